@@ -1,0 +1,187 @@
+/*
+ * rfa.h — C ABI of librfa_hip.so, the MI355X (gfx950) attention operator library.
+ *
+ * This is the drop-in boundary of the hot path.  Each entry point replaces one private
+ * function of the (un-vendored, CUDA-only) `flash_attn.flash_attn_interface` module that the
+ * reference calls, or one eager/Triton helper of the reference itself:
+ *
+ *   rfa_fwd            <- flash_attn._flash_attn_forward          (call sites
+ *                         /root/reference/ring_flash_attn/ring_flash_attn.py:53,
+ *                         zigzag_ring_flash_attn.py:52) and
+ *                         flash_attn._flash_attn_varlen_forward   (ring_flash_attn_varlen.py:77,
+ *                         zigzag_ring_flash_attn_varlen.py:137, llama3_flash_attn_varlen.py:147)
+ *                         plus, when `out_acc/lse_acc` are given, the fused form of
+ *                         update_out_and_lse (ring_flash_attn/utils.py:32-73).
+ *   rfa_bwd_preprocess <- the rowsum(dO*O) prologue inside flash_attn._flash_attn_backward.
+ *   rfa_bwd            <- flash_attn._flash_attn_backward          (ring_flash_attn.py:131,
+ *                         zigzag_ring_flash_attn.py:156) and _flash_attn_varlen_backward
+ *                         (ring_flash_attn_varlen.py:169, zigzag_ring_flash_attn_varlen.py:275,
+ *                         llama3_flash_attn_varlen.py:282), plus, when `*_acc` are given, the
+ *                         fp32 `dq += ...`, `dk += ...` accumulation of
+ *                         zigzag_ring_flash_attn.py:164-187 / ring_flash_attn.py:134-141.
+ *   rfa_merge          <- _update_out_and_lse (ring_flash_attn/utils.py:32-50) as a stand-alone
+ *                         kernel (also covers the slice_ variant, utils.py:65-70).
+ *   rfa_lse_flatten / rfa_lse_unflatten
+ *                      <- triton_utils.flatten_varlen_lse / unflatten_varlen_lse
+ *                         (ring_flash_attn/triton_utils.py:39-67,103-137).
+ *   rfa_cast           <- `out.to(q.dtype)` / `dq.to(q.dtype)` tails (zigzag_ring_flash_attn.py:86,199).
+ *
+ * Conventions
+ *   - Plain C, no torch types.  All pointers are DEVICE pointers owned by the caller.  The
+ *     library never allocates, frees or synchronises; every launch goes to the `stream`
+ *     argument (a hipStream_t passed as void*).
+ *   - All strides are in ELEMENTS of the tensor's own dtype.  The innermost (head_dim) stride
+ *     must be 1 and every row start must be 16-byte aligned.
+ *   - Dense mode (cu_seqlens_* == NULL):  q is (B, Sq, H, D), k/v are (B, Sk, Hk, D), lse is
+ *     (B, H, Sq).  Varlen mode: q is (Tq, H, D), k/v (Tk, Hk, D), lse is (H, Tq); `B` is the
+ *     number of packed sequences, `Sq`/`Sk` the max sequence lengths, *_batch strides unused.
+ *   - Causal masks are bottom-right aligned: key j is visible to query i iff
+ *     j <= i + (len_k - len_q)  (flash_attn >= 2.1 semantics).
+ *   - Rows with no visible key produce out = 0 and lse = +inf (flash_attn semantics); in
+ *     accumulate mode such rows leave the accumulators untouched.
+ *   - `q_half` / `k_half` select, per packed (or dense) sequence, the whole sequence (0), its
+ *     front half (1) or its back half (2) WITHOUT gathering — the offset arithmetic that
+ *     replaces get_half_index/get_half_lse (zigzag_ring_flash_attn_varlen.py:24-71).  Outputs
+ *     (out, lse, dq, delta) are addressed like q; dk/dv like k.
+ *   - Return value: 0 on success, negative rfa_status otherwise; rfa_strerror() explains.
+ */
+#ifndef RFA_H_
+#define RFA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFA_ABI_VERSION 1
+
+typedef enum {
+  RFA_OK = 0,
+  RFA_ERR_NULL = -1,        /* required pointer is NULL                       */
+  RFA_ERR_DTYPE = -2,       /* dtype not RFA_BF16 / RFA_F16                    */
+  RFA_ERR_HEAD_DIM = -3,    /* head_dim not a multiple of 8 or > 128           */
+  RFA_ERR_HEADS = -4,       /* H not a multiple of Hk                          */
+  RFA_ERR_SHAPE = -5,       /* negative / zero extents                         */
+  RFA_ERR_ALIGN = -6,       /* pointer or stride breaks the 16-byte contract   */
+  RFA_ERR_LAUNCH = -7,      /* hipLaunchKernel reported an error               */
+  RFA_ERR_ARGS = -8         /* inconsistent flag / pointer combination         */
+} rfa_status;
+
+typedef enum { RFA_BF16 = 0, RFA_F16 = 1 } rfa_dtype;
+
+enum { RFA_HALF_FULL = 0, RFA_HALF_FRONT = 1, RFA_HALF_BACK = 2 };
+
+/* (batch, row, head) element strides of a (B, S, H, D) / (T, H, D) tensor */
+typedef struct {
+  int64_t batch;
+  int64_t row;
+  int64_t head;
+} rfa_strides;
+
+typedef struct {
+  /* inputs */
+  const void *q, *k, *v;
+  rfa_strides q_st, k_st, v_st;
+  /* plain outputs (io dtype out, fp32 lse).  Used when out_acc == NULL. */
+  void *out;
+  rfa_strides out_st;
+  float *lse;              /* (B,H,Sq) or (H,Tq) */
+  int64_t lse_batch, lse_head; /* element strides; row stride is 1 */
+  /* fused online-merge accumulators (fp32).  When non-NULL the kernel merges its block
+   * result into them instead of writing out/lse:  out_acc has out's logical shape,
+   * lse_acc has lse's.  acc_init != 0: first block of a ring — overwrite, do not read. */
+  float *out_acc;
+  rfa_strides out_acc_st;
+  float *lse_acc;
+  int64_t lse_acc_batch, lse_acc_head;
+  int32_t acc_init;
+  /* varlen */
+  const int32_t *cu_seqlens_q, *cu_seqlens_k; /* (B+1,) int32 device, or NULL */
+  int32_t q_half, k_half;
+  /* shape */
+  int32_t B, H, Hk, D, Sq, Sk;
+  float softmax_scale;
+  int32_t causal;
+  int32_t dtype; /* rfa_dtype */
+} rfa_fwd_args;
+
+typedef struct {
+  const void *dout, *out; /* (B,Sq,H,D) io dtype */
+  rfa_strides dout_st, out_st;
+  float *delta;           /* same layout contract as lse */
+  int64_t delta_batch, delta_head;
+  const int32_t *cu_seqlens_q;
+  int32_t q_half;
+  int32_t B, H, D, Sq;
+  int32_t dtype;
+} rfa_bwd_preprocess_args;
+
+typedef struct {
+  const void *dout, *q, *k, *v;
+  rfa_strides dout_st, q_st, k_st, v_st;
+  const float *lse;   /* GLOBAL log-sum-exp of the rows (natural log)            */
+  int64_t lse_batch, lse_head;
+  const float *delta; /* rowsum(dout*out), from rfa_bwd_preprocess              */
+  int64_t delta_batch, delta_head;
+  /* plain outputs in io dtype (used when the matching *_acc pointer is NULL) */
+  void *dq, *dk, *dv;
+  rfa_strides dq_st, dk_st, dv_st;
+  /* fp32 accumulators: dq_acc += dq ; dk_acc += dk ; dv_acc += dv  (acc_init: overwrite) */
+  float *dq_acc, *dk_acc, *dv_acc;
+  rfa_strides dq_acc_st, dk_acc_st, dv_acc_st;
+  int32_t acc_init;
+  /* workspace for per-q-head dK/dV partials, io dtype, 2 * B*Sk_total*H*D elements
+   * (rfa_bwd_workspace_bytes).  May be NULL iff H == Hk and dk_acc == NULL. */
+  void *workspace;
+  const int32_t *cu_seqlens_q, *cu_seqlens_k;
+  int32_t q_half, k_half;
+  int32_t B, H, Hk, D, Sq, Sk;
+  int64_t total_k;    /* varlen: number of packed k rows addressed (Tk); dense: B*Sk */
+  float softmax_scale;
+  int32_t causal;
+  int32_t deterministic; /* accepted; this implementation is always deterministic */
+  int32_t dtype;
+} rfa_bwd_args;
+
+typedef struct {
+  float *out_acc;          /* (B,S,H,D) fp32, updated in place */
+  rfa_strides out_acc_st;
+  float *lse_acc;          /* (B,H,S) fp32, updated in place   */
+  int64_t lse_acc_batch, lse_acc_head;
+  const void *block_out;   /* io dtype */
+  rfa_strides block_out_st;
+  const float *block_lse;  /* (B,H,S) */
+  int64_t block_lse_batch, block_lse_head;
+  int32_t B, H, D, S;      /* S rows are merged (pass slice pointers for a row range) */
+  int32_t acc_init;
+  int32_t dtype;
+} rfa_merge_args;
+
+int rfa_abi_version(void);
+const char *rfa_strerror(int status);
+
+int rfa_fwd(const rfa_fwd_args *args, void *stream);
+int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
+int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
+int rfa_bwd(const rfa_bwd_args *args, void *stream);
+int rfa_merge(const rfa_merge_args *args, void *stream);
+
+/* dst(io dtype) = (io)src(fp32), n elements, both contiguous */
+int rfa_cast(void *dst, const float *src, int64_t n, int32_t dtype, void *stream);
+
+/* LSE re-layout, fp32 (triton_utils.py:39-67,103-137).  The padded tensor is a contiguous
+ * (B, H, max_seqlen); the packed tensor has element (h, t) at h*head_stride + t*row_stride, so
+ * it covers both the (H, T) result of flatten and the (T, H, 1) input of unflatten.
+ * Padding positions of the unflatten destination are left untouched (as the reference does). */
+int rfa_lse_flatten(float *dst_packed, const float *src_padded, const int32_t *cu_seqlens,
+                    int32_t B, int32_t H, int32_t max_seqlen, int64_t dst_head_stride,
+                    int64_t dst_row_stride, void *stream);
+int rfa_lse_unflatten(float *dst_padded, const float *src_packed, const int32_t *cu_seqlens,
+                      int32_t B, int32_t H, int32_t max_seqlen, int64_t src_head_stride,
+                      int64_t src_row_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFA_H_ */

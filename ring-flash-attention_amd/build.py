@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Build recipe for the MI355X ring flash-attention library (gfx950 only).
+
+Targets (all in-tree, so the artefacts travel with the repo snapshot to the GPU box):
+  lib      ring-flash-attention_amd/ring_flash_attn/librfa_hip.so   hipcc, HIP kernels + C ABI
+  oracle   oracle/libattn_ref.so                                     gcc -fopenmp, CPU checker
+  selftest tests/native/selftest                                     hipcc, torch-free GPU test
+
+`python ring-flash-attention_amd/build.py [lib] [oracle] [selftest] [--force]`
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ring-flash-attention_amd")
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "ring_flash_attn", "librfa_hip.so")
+ORACLE_SRC = os.path.join(ROOT, "oracle", "attn_ref.c")
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libattn_ref.so")
+SELFTEST_SRC = os.path.join(ROOT, "tests", "native", "selftest.cpp")
+SELFTEST_BIN = os.path.join(ROOT, "tests", "native", "selftest")
+
+HIP_SOURCES = ["rfa_fwd.hip", "rfa_bwd.hip", "rfa_aux.hip"]
+API_SOURCE = "rfa_api.cpp"
+HEADERS = ["rfa_common.hpp", "rfa_kernels.hpp", os.path.join(ROOT, "include", "rfa.h")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build librfa_hip.so)")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, cwd=cwd, check=True)
+
+
+def build_lib(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES + [API_SOURCE]]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fno-gpu-rdc", "-Wno-unused-result"]
+    cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
+    cmd += ["-o", LIB]
+    _run(cmd)
+    return LIB
+
+
+def build_oracle(force=False):
+    if not force and not _stale(ORACLE_LIB, [ORACLE_SRC]):
+        return ORACLE_LIB
+    _run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", ORACLE_SRC,
+          "-o", ORACLE_LIB, "-lm"])
+    return ORACLE_LIB
+
+
+def build_selftest(force=False):
+    build_lib(force)
+    build_oracle(force)
+    deps = [SELFTEST_SRC, LIB, ORACLE_LIB, os.path.join(CSRC, "rfa_common.hpp")]
+    if not force and not _stale(SELFTEST_BIN, deps):
+        return SELFTEST_BIN
+    _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", SELFTEST_SRC, "-o", SELFTEST_BIN,
+          "-L" + os.path.dirname(LIB), "-lrfa_hip", "-L" + os.path.dirname(ORACLE_LIB), "-lattn_ref",
+          "-Wl,-rpath,$ORIGIN/../../ring-flash-attention_amd/ring_flash_attn",
+          "-Wl,-rpath,$ORIGIN/../../oracle"])
+    return SELFTEST_BIN
+
+
+def main(argv):
+    force = "--force" in argv
+    targets = [a for a in argv if not a.startswith("-")] or ["lib", "oracle"]
+    for t in targets:
+        {"lib": build_lib, "oracle": build_oracle, "selftest": build_selftest}[t](force)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,238 @@
+// rfa_api.cpp — the C ABI of librfa_hip.so (see include/rfa.h for the contract and for the
+// reference call sites each entry point replaces).  Pure argument checking + parameter
+// translation; no allocation, no synchronisation, launches only on the caller's stream.
+#include "../../include/rfa.h"
+#include "rfa_kernels.hpp"
+
+using namespace rfa;
+
+namespace {
+
+inline Strides cv(const rfa_strides& s) { return Strides{s.batch, s.row, s.head}; }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// element strides must keep every row start 16-byte aligned
+inline bool stride_ok(const rfa_strides& s, int elt_bytes) {
+  const int64_t q = 16 / elt_bytes;
+  return (s.row % q) == 0 && (s.head % q) == 0 && (s.batch % q) == 0;
+}
+
+inline int check_common(int dtype, int H, int Hk, int D, int B) {
+  if (dtype != RFA_BF16 && dtype != RFA_F16) return RFA_ERR_DTYPE;
+  if (D <= 0 || D > kHeadDim || (D % 8) != 0) return RFA_ERR_HEAD_DIM;
+  if (H <= 0 || Hk <= 0 || (H % Hk) != 0) return RFA_ERR_HEADS;
+  if (B < 0) return RFA_ERR_SHAPE;
+  return RFA_OK;
+}
+
+inline int eff_len(int S, int half) { return half == RFA_HALF_FULL ? S : (S + 1) / 2; }
+
+}  // namespace
+
+extern "C" {
+
+int rfa_abi_version(void) { return RFA_ABI_VERSION; }
+
+const char* rfa_strerror(int status) {
+  switch (status) {
+    case RFA_OK: return "ok";
+    case RFA_ERR_NULL: return "a required pointer is NULL";
+    case RFA_ERR_DTYPE: return "unsupported dtype (only bf16 / fp16)";
+    case RFA_ERR_HEAD_DIM: return "head_dim must be a multiple of 8 and <= 128";
+    case RFA_ERR_HEADS: return "nheads must be a positive multiple of nheads_k";
+    case RFA_ERR_SHAPE: return "negative or inconsistent extent";
+    case RFA_ERR_ALIGN: return "pointer/stride violates the 16-byte alignment contract";
+    case RFA_ERR_LAUNCH: return "HIP kernel launch failed";
+    case RFA_ERR_ARGS: return "inconsistent flag / pointer combination";
+    default: return "unknown rfa status";
+  }
+}
+
+int rfa_fwd(const rfa_fwd_args* a, void* stream) {
+  if (!a) return RFA_ERR_NULL;
+  int rc = check_common(a->dtype, a->H, a->Hk, a->D, a->B);
+  if (rc) return rc;
+  if (a->Sq < 0 || a->Sk < 0) return RFA_ERR_SHAPE;
+  if (a->B == 0 || a->Sq == 0) return RFA_OK;
+  if (!a->q || !a->k || !a->v) return RFA_ERR_NULL;
+  if (a->out_acc) {
+    if (!a->lse_acc) return RFA_ERR_NULL;
+  } else if (!a->out || !a->lse) {
+    return RFA_ERR_NULL;
+  }
+  if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
+  if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v)) return RFA_ERR_ALIGN;
+  if (!stride_ok(a->q_st, 2) || !stride_ok(a->k_st, 2) || !stride_ok(a->v_st, 2)) return RFA_ERR_ALIGN;
+  if (a->out_acc) {
+    if (!aligned16(a->out_acc) || !stride_ok(a->out_acc_st, 4)) return RFA_ERR_ALIGN;
+  } else {
+    if ((reinterpret_cast<uintptr_t>(a->out) & 7) || (a->out_st.row % 4) || (a->out_st.head % 4) ||
+        (a->out_st.batch % 4))
+      return RFA_ERR_ALIGN;
+  }
+  FwdParams p{};
+  p.q = a->q; p.k = a->k; p.v = a->v;
+  p.out = a->out; p.lse = a->lse;
+  p.out_acc = a->out_acc; p.lse_acc = a->lse_acc;
+  p.cu_q = a->cu_seqlens_q; p.cu_k = a->cu_seqlens_k;
+  p.q_st = cv(a->q_st); p.k_st = cv(a->k_st); p.v_st = cv(a->v_st);
+  p.out_st = cv(a->out_st); p.out_acc_st = cv(a->out_acc_st);
+  p.lse_batch = a->lse_batch; p.lse_head = a->lse_head;
+  p.lse_acc_batch = a->lse_acc_batch; p.lse_acc_head = a->lse_acc_head;
+  p.B = a->B; p.H = a->H; p.Hk = a->Hk; p.D = a->D; p.Sq = a->Sq; p.Sk = a->Sk;
+  p.q_half = a->q_half; p.k_half = a->k_half;
+  p.causal = a->causal ? 1 : 0; p.acc_init = a->acc_init ? 1 : 0;
+  p.scale = a->softmax_scale;
+  const int rows = fwd_qrows_per_block();
+  p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
+  return launch_fwd(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {
+  if (!a) return RFA_ERR_NULL;
+  int rc = check_common(a->dtype, a->H, a->H, a->D, a->B);
+  if (rc) return rc;
+  if (a->Sq < 0) return RFA_ERR_SHAPE;
+  if (a->B == 0 || a->Sq == 0) return RFA_OK;
+  if (!a->dout || !a->out || !a->delta) return RFA_ERR_NULL;
+  if (!aligned16(a->dout) || !aligned16(a->out) || !stride_ok(a->dout_st, 2) || !stride_ok(a->out_st, 2))
+    return RFA_ERR_ALIGN;
+  PreParams p{};
+  p.dout = a->dout; p.out = a->out; p.delta = a->delta; p.cu_q = a->cu_seqlens_q;
+  p.dout_st = cv(a->dout_st); p.out_st = cv(a->out_st);
+  p.delta_batch = a->delta_batch; p.delta_head = a->delta_head;
+  p.B = a->B; p.H = a->H; p.D = a->D; p.Sq = a->Sq; p.q_half = a->q_half;
+  return launch_preprocess(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+static bool bwd_needs_ws(const rfa_bwd_args* a) { return a->H != a->Hk || a->dk_acc != nullptr; }
+
+int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
+  if (!a || !bwd_needs_ws(a)) return 0;
+  return 2 * a->total_k * (int64_t)a->H * a->D * 2;
+}
+
+int rfa_bwd(const rfa_bwd_args* a, void* stream) {
+  if (!a) return RFA_ERR_NULL;
+  int rc = check_common(a->dtype, a->H, a->Hk, a->D, a->B);
+  if (rc) return rc;
+  if (a->Sq < 0 || a->Sk < 0) return RFA_ERR_SHAPE;
+  if (a->B == 0 || a->Sq == 0 || a->Sk == 0) return RFA_OK;
+  if (!a->dout || !a->q || !a->k || !a->v || !a->lse || !a->delta) return RFA_ERR_NULL;
+  if (!a->dq && !a->dq_acc) return RFA_ERR_NULL;
+  if ((a->dk_acc == nullptr) != (a->dv_acc == nullptr)) return RFA_ERR_ARGS;
+  if (!a->dk_acc && (!a->dk || !a->dv)) return RFA_ERR_NULL;
+  if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
+  const bool ws = bwd_needs_ws(a);
+  if (ws && !a->workspace) return RFA_ERR_NULL;
+  if (!aligned16(a->dout) || !aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v))
+    return RFA_ERR_ALIGN;
+  if (!stride_ok(a->dout_st, 2) || !stride_ok(a->q_st, 2) || !stride_ok(a->k_st, 2) || !stride_ok(a->v_st, 2))
+    return RFA_ERR_ALIGN;
+  if (a->dq_acc && (!aligned16(a->dq_acc) || !stride_ok(a->dq_acc_st, 4))) return RFA_ERR_ALIGN;
+  if (a->dk_acc && (!aligned16(a->dk_acc) || !aligned16(a->dv_acc) || !stride_ok(a->dk_acc_st, 4) ||
+                    !stride_ok(a->dv_acc_st, 4)))
+    return RFA_ERR_ALIGN;
+  if (!a->dk_acc && (!aligned16(a->dk) || !aligned16(a->dv) || !stride_ok(a->dk_st, 2) || !stride_ok(a->dv_st, 2)))
+    return RFA_ERR_ALIGN;
+
+  hipStream_t st = (hipStream_t)stream;
+  BwdParams p{};
+  p.dout = a->dout; p.q = a->q; p.k = a->k; p.v = a->v; p.lse = a->lse; p.delta = a->delta;
+  p.dq = a->dq; p.dq_acc = a->dq_acc;
+  p.cu_q = a->cu_seqlens_q; p.cu_k = a->cu_seqlens_k;
+  p.dout_st = cv(a->dout_st); p.q_st = cv(a->q_st); p.k_st = cv(a->k_st); p.v_st = cv(a->v_st);
+  p.dq_st = cv(a->dq_st); p.dq_acc_st = cv(a->dq_acc_st);
+  p.lse_batch = a->lse_batch; p.lse_head = a->lse_head;
+  p.delta_batch = a->delta_batch; p.delta_head = a->delta_head;
+  p.B = a->B; p.H = a->H; p.Hk = a->Hk; p.D = a->D; p.Sq = a->Sq; p.Sk = a->Sk;
+  p.q_half = a->q_half; p.k_half = a->k_half;
+  p.causal = a->causal ? 1 : 0; p.acc_init = a->acc_init ? 1 : 0;
+  p.scale = a->softmax_scale;
+  p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();
+  p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block() - 1) / bwd_dkdv_keys_per_block();
+
+  Strides ws_st{};
+  if (ws) {
+    // partials: (rows, H, D) contiguous; dense rows = b*Sk + row (own batch stride)
+    ws_st.head = a->D;
+    ws_st.row = (int64_t)a->H * a->D;
+    ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->H * a->D;
+    p.dk = a->workspace;
+    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->H * a->D * 2;
+    p.dk_st = ws_st; p.dv_st = ws_st;
+  } else {
+    p.dk = a->dk; p.dv = a->dv;
+    p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
+  }
+  if (launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+  if (launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+  if (ws) {
+    for (int which = 0; which < 2; ++which) {
+      ReduceParams r{};
+      r.src = which ? p.dv : p.dk;
+      r.src_st = ws_st;
+      r.cu_k = a->cu_seqlens_k;
+      r.B = a->B; r.Hk = a->Hk; r.G = a->H / a->Hk; r.D = a->D; r.Sk = a->Sk;
+      r.k_half = a->k_half; r.acc_init = a->acc_init ? 1 : 0;
+      if (a->dk_acc) {
+        r.dst_acc = which ? a->dv_acc : a->dk_acc;
+        r.dst_acc_st = cv(which ? a->dv_acc_st : a->dk_acc_st);
+      } else {
+        r.dst = which ? a->dv : a->dk;
+        r.dst_st = cv(which ? a->dv_st : a->dk_st);
+      }
+      if (launch_reduce(r, a->dtype, st)) return RFA_ERR_LAUNCH;
+    }
+  }
+  return RFA_OK;
+}
+
+int rfa_merge(const rfa_merge_args* a, void* stream) {
+  if (!a) return RFA_ERR_NULL;
+  int rc = check_common(a->dtype, a->H, a->H, a->D, a->B);
+  if (rc) return rc;
+  if (a->S < 0) return RFA_ERR_SHAPE;
+  if (a->B == 0 || a->S == 0) return RFA_OK;
+  if (!a->out_acc || !a->lse_acc || !a->block_out || !a->block_lse) return RFA_ERR_NULL;
+  if (!aligned16(a->out_acc) || !aligned16(a->block_out) || !stride_ok(a->out_acc_st, 4) ||
+      !stride_ok(a->block_out_st, 2))
+    return RFA_ERR_ALIGN;
+  MergeParams p{};
+  p.out_acc = a->out_acc; p.lse_acc = a->lse_acc; p.block_out = a->block_out; p.block_lse = a->block_lse;
+  p.out_acc_st = cv(a->out_acc_st); p.block_out_st = cv(a->block_out_st);
+  p.lse_acc_batch = a->lse_acc_batch; p.lse_acc_head = a->lse_acc_head;
+  p.block_lse_batch = a->block_lse_batch; p.block_lse_head = a->block_lse_head;
+  p.B = a->B; p.H = a->H; p.D = a->D; p.S = a->S; p.acc_init = a->acc_init ? 1 : 0;
+  return launch_merge(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+int rfa_cast(void* dst, const float* src, int64_t n, int32_t dtype, void* stream) {
+  if (dtype != RFA_BF16 && dtype != RFA_F16) return RFA_ERR_DTYPE;
+  if (n < 0) return RFA_ERR_SHAPE;
+  if (n == 0) return RFA_OK;
+  if (!dst || !src) return RFA_ERR_NULL;
+  if (!aligned16(dst) || !aligned16(src)) return RFA_ERR_ALIGN;
+  return launch_cast(dst, src, n, dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+int rfa_lse_flatten(float* dst, const float* src, const int32_t* cu_seqlens, int32_t B, int32_t H,
+                    int32_t max_seqlen, int64_t dst_head_stride, int64_t dst_row_stride, void* stream) {
+  if (B < 0 || H < 0 || max_seqlen < 0) return RFA_ERR_SHAPE;
+  if (B == 0 || H == 0 || max_seqlen == 0) return RFA_OK;
+  if (!dst || !src || !cu_seqlens) return RFA_ERR_NULL;
+  return launch_lse_relayout(dst, src, cu_seqlens, B, H, max_seqlen, dst_head_stride, dst_row_stride,
+                             true, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+int rfa_lse_unflatten(float* dst, const float* src, const int32_t* cu_seqlens, int32_t B, int32_t H,
+                      int32_t max_seqlen, int64_t src_head_stride, int64_t src_row_stride, void* stream) {
+  if (B < 0 || H < 0 || max_seqlen < 0) return RFA_ERR_SHAPE;
+  if (B == 0 || H == 0 || max_seqlen == 0) return RFA_OK;
+  if (!dst || !src || !cu_seqlens) return RFA_ERR_NULL;
+  return launch_lse_relayout(dst, src, cu_seqlens, B, H, max_seqlen, src_head_stride, src_row_stride,
+                             false, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// rfa_bwd.hip — flash-attention backward for gfx950 (MI355X): dQ kernel + dK/dV kernel.
+//
+// Replaces flash_attn._flash_attn_backward / _flash_attn_varlen_backward as called from
+// /root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:156, ring_flash_attn.py:131,
+// ring_flash_attn_varlen.py:169, zigzag_ring_flash_attn_varlen.py:275,
+// llama3_flash_attn_varlen.py:282.  Math (per head, P uses the GLOBAL lse of the row):
+//     P  = exp(scale·QKᵀ − lse)          dP = dO·Vᵀ          dS = P ∘ (dP − Δ),  Δ = rowsum(dO∘O)
+//     dQ = scale·dS·K        dK = scale·dSᵀ·Q        dV = Pᵀ·dO
+// Deterministic by construction: no atomics.  The work is split by OUTPUT ownership:
+//   * dq_kernel    : a workgroup owns 256 query rows, streams K/V tiles through LDS
+//                    (S,dP recomputed per tile), accumulates dQ in registers, and either
+//                    stores it or adds it into a caller fp32 accumulator (ring steps).
+//   * dkdv_kernel  : a workgroup owns 128 keys of ONE query head, streams Q/dO tiles through
+//                    LDS, accumulates dK,dV in registers (4 waves x 32 keys, 512-register
+//                    budget).  GQA group reduction is a separate HBM-bound kernel
+//                    (rfa_aux.hip: reduce_kernel), like flash_attn's dk_expanded + sum.
+// Lane ownership mirrors the forward kernel (see rfa_common.hpp): after the first GEMM a
+// lane owns one query row (dQ kernel) or one key (dK/dV kernel), and the probabilities go
+// straight from the accumulator registers into the B operand of the second GEMM.
+#include "rfa_common.hpp"
+#include "rfa_kernels.hpp"
+
+namespace rfa {
+
+// =====================================================================================
+// dQ kernel
+// =====================================================================================
+constexpr int kDqWaves = 8;
+constexpr int kDqThreads = kDqWaves * 64;
+constexpr int kDqRows = kDqWaves * 32;          // 256 query rows / workgroup
+constexpr int kDqKV = 64;
+constexpr int kDqTileBytes = kDqKV * kRowBytes; // 16 KiB
+constexpr int kDqSmem = 4 * kDqTileBytes;       // K[2] V[2]
+
+template <typename T>
+__global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int gq = idx % G;
+  idx /= G;
+  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
+  const int b = idx / p.nqblk;
+  const int h = hk * G + gq;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int qwg0 = qblk * kDqRows;
+  if (qwg0 >= lq) return;
+  const int off = lk - lq;
+  const int qw0 = qwg0 + wave * 32;
+  const int qrow = qw0 + l31;
+  const int qrow_c = qrow < lq ? qrow : lq - 1;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+  const int64_t arow = qs.row0 + qrow_c;
+
+  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + arow * p.q_st.row + (int64_t)h * p.q_st.head;
+  const T* dobase = (const T*)p.dout + qbatch * p.dout_st.batch + arow * p.dout_st.row +
+                    (int64_t)h * p.dout_st.head;
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
+
+  vec8<T> qf[8], dof[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int d0 = 16 * kk + 8 * g;
+    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+    dof[kk] = d0 < p.D ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
+  }
+  const float L2 = p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + arow] * kLog2e;
+  const float dlt = p.delta[qbatch * p.delta_batch + (int64_t)h * p.delta_head + arow];
+
+  const int qend = (qwg0 + kDqRows < lq) ? qwg0 + kDqRows : lq;
+  int kmax = lk;
+  if (p.causal && qend + off < kmax) kmax = qend + off;
+  const int ntiles = kmax > 0 ? (kmax + kDqKV - 1) / kDqKV : 0;
+
+  const int sc = tid & 15;
+  const int sr = tid >> 4;
+  const bool sd_ok = sc * 8 < p.D;
+  vec8<T> kreg[2], vreg[2];
+  auto load_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kr = j * kDqKV + sr + 32 * i;
+      kr = kr < lk ? kr : lk - 1;
+      if (sd_ok) {
+        kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
+        vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
+      } else {
+        kreg[i] = zero8<T>();
+        vreg[i] = zero8<T>();
+      }
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = tile_off(sr + 32 * i, sc);
+      lds_write128<T>(smem + buf * kDqTileBytes + o, kreg[i]);
+      lds_write128<T>(smem + (2 + buf) * kDqTileBytes + o, vreg[i]);
+    }
+  };
+
+  int koff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) koff[kk] = tile_off(l31, 2 * kk + g);
+  int toff[4][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+      toff[dblk][hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
+                       tr_lane_off(lane, dblk, (2 * hh + g) & 3);
+
+  const float c = p.scale * kLog2e;
+  f32x16 dq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  if (ntiles > 0) {
+    load_tile(0);
+    write_tile(0);
+  }
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int buf = j & 1;
+    lds_t* kb = smem + buf * kDqTileBytes;
+    lds_t* vb = smem + (2 + buf) * kDqTileBytes;
+    if (j + 1 < ntiles) load_tile(j + 1);
+    const int kt0 = j * kDqKV;
+    const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
+    if (active) {
+      const bool need_mask = (kt0 + kDqKV > lk) || (p.causal && kt0 + kDqKV - 1 > qw0 + off);
+      const int lim = p.causal ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          vec8<T> a = lds_read128<T>(kb + t * 32 * kRowBytes + koff[kk]);
+          s = mfma(a, qf[kk], s);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          vec8<T> a = lds_read128<T>(vb + t * 32 * kRowBytes + koff[kk]);
+          dp = mfma(a, dof[kk], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = fast_exp2(__builtin_fmaf(s[r], c, -L2));
+          if (need_mask) {
+            const int key = kt0 + 32 * t + crow(r, g);
+            pv = key > lim ? 0.f : pv;
+          }
+          s[r] = pv * (dp[r] - dlt);
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const vec8<T> dsb = pack8<T>(s, 8 * ks2);
+          lds_t* kt = kb + (32 * t + 16 * ks2) * kRowBytes;
+#pragma unroll
+          for (int dblk = 0; dblk < 4; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(kt + toff[dblk][0]);
+            vec4<T> hi = lds_read_tr<T>(kt + toff[dblk][1]);
+            dq[dblk] = mfma(concat<T>(lo, hi), dsb, dq[dblk]);
+          }
+        }
+      }
+    }
+    if (j + 1 < ntiles) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (qrow >= lq) return;
+  const int64_t orow = qs.row0 + qrow;
+  if (p.dq_acc == nullptr) {
+    T* ob = (T*)p.dq + qbatch * p.dq_st.batch + orow * p.dq_st.row + (int64_t)h * p.dq_st.head;
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (d0 < p.D) {
+          f32x4 x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = dq[dblk][4 * jj + e] * p.scale;
+          *(vec4<T>*)(ob + d0) = __builtin_convertvector(x, vec4<T>);
+        }
+      }
+  } else {
+    float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + orow * p.dq_acc_st.row +
+                (int64_t)h * p.dq_acc_st.head;
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (d0 < p.D) {
+          f32x4 x;
+          if (p.acc_init) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = 0.f;
+          } else {
+            x = *(f32x4*)(ab + d0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] += dq[dblk][4 * jj + e] * p.scale;
+          *(f32x4*)(ab + d0) = x;
+        }
+      }
+  }
+}
+
+// =====================================================================================
+// dK/dV kernel
+// =====================================================================================
+constexpr int kKvWaves = 4;
+constexpr int kKvThreads = kKvWaves * 64;
+constexpr int kKvKeys = kKvWaves * 32;           // 128 keys / workgroup
+constexpr int kKvQ = 64;                          // query rows per tile
+constexpr int kKvTileBytes = kKvQ * kRowBytes;    // 16 KiB
+constexpr int kKvStatBytes = 2 * kKvQ * 4;        // lse2[64] + delta[64] per stage
+constexpr int kKvSmem = 4 * kKvTileBytes + 2 * kKvStatBytes;   // Q[2] dO[2] stats[2]
+
+template <typename T>
+__global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  lds_t* stat_base = smem + 4 * kKvTileBytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int gq = idx % G;
+  idx /= G;
+  const int kblk = idx % p.nkblk;                 // early keys see most queries: heavy first
+  const int b = idx / p.nkblk;
+  const int h = hk * G + gq;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int kwg0 = kblk * kKvKeys;
+  if (kwg0 >= lk) return;
+  const int off = lk - lq;
+  const int kw0 = kwg0 + wave * 32;
+  const int krow = kw0 + l31;
+  const int krow_c = krow < lk ? krow : lk - 1;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + (ks.row0 + krow_c) * p.k_st.row +
+                   (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + (ks.row0 + krow_c) * p.v_st.row +
+                   (int64_t)hk * p.v_st.head;
+  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + qs.row0 * p.q_st.row + (int64_t)h * p.q_st.head;
+  const T* dobase = (const T*)p.dout + qbatch * p.dout_st.batch + qs.row0 * p.dout_st.row +
+                    (int64_t)h * p.dout_st.head;
+  const float* lsebase = p.lse + qbatch * p.lse_batch + (int64_t)h * p.lse_head + qs.row0;
+  const float* dltbase = p.delta + qbatch * p.delta_batch + (int64_t)h * p.delta_head + qs.row0;
+
+  // K_w / V_w fragments: B operands (lane key = l31, d = 16kk + 8g .. +7)
+  vec8<T> kf[8], vf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int d0 = 16 * kk + 8 * g;
+    kf[kk] = d0 < p.D ? *(const vec8<T>*)(kbase + d0) : zero8<T>();
+    vf[kk] = d0 < p.D ? *(const vec8<T>*)(vbase + d0) : zero8<T>();
+  }
+
+  // query tile range: causal => only rows q with q + off >= first key of the block
+  int qfirst = 0;
+  if (p.causal) {
+    qfirst = kwg0 - off;
+    if (qfirst < 0) qfirst = 0;
+  }
+  const int jt0 = qfirst / kKvQ;
+  const int jt1 = (lq + kKvQ - 1) / kKvQ;     // exclusive
+
+  // staging: thread -> chunk sc of rows sr + 16 i (i = 0..3), for Q and dO
+  const int sc = tid & 15;
+  const int sr = tid >> 4;                    // 0..15
+  const bool sd_ok = sc * 8 < p.D;
+  vec8<T> qreg[4], doreg[4];
+  float statreg = 0.f;
+  auto load_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int qr = j * kKvQ + sr + 16 * i;
+      qr = qr < lq ? qr : lq - 1;
+      if (sd_ok) {
+        qreg[i] = *(const vec8<T>*)(qbase + (int64_t)qr * p.q_st.row + sc * 8);
+        doreg[i] = *(const vec8<T>*)(dobase + (int64_t)qr * p.dout_st.row + sc * 8);
+      } else {
+        qreg[i] = zero8<T>();
+        doreg[i] = zero8<T>();
+      }
+    }
+    if (tid < 2 * kKvQ) {
+      int qr = j * kKvQ + (tid & (kKvQ - 1));
+      qr = qr < lq ? qr : lq - 1;
+      statreg = tid < kKvQ ? lsebase[qr] * kLog2e : dltbase[qr];
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = tile_off(sr + 16 * i, sc);
+      lds_write128<T>(smem + buf * kKvTileBytes + o, qreg[i]);
+      lds_write128<T>(smem + (2 + buf) * kKvTileBytes + o, doreg[i]);
+    }
+    if (tid < 2 * kKvQ)
+      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) = statreg;
+  };
+
+  int aoff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) aoff[kk] = tile_off(l31, 2 * kk + g);
+  int toff[4][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+      toff[dblk][hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
+                       tr_lane_off(lane, dblk, (2 * hh + g) & 3);
+
+  const float c = p.scale * kLog2e;
+  f32x16 dk[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  if (jt0 < jt1) {
+    load_tile(jt0);
+    write_tile(0);
+  }
+  __syncthreads();
+
+  for (int j = jt0; j < jt1; ++j) {
+    const int buf = (j - jt0) & 1;
+    lds_t* qb = smem + buf * kKvTileBytes;
+    lds_t* dob = smem + (2 + buf) * kKvTileBytes;
+    lds_t* st = stat_base + buf * kKvStatBytes;
+    if (j + 1 < jt1) load_tile(j + 1);
+    const int qt0 = j * kKvQ;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qs0 = qt0 + 32 * t;
+      // sub-tile entirely above the diagonal for this wave's keys, or entirely past lq
+      const bool active = (kw0 < lk) && (qs0 < lq) && !(p.causal && qs0 + 31 + off < kw0);
+      if (active) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          vec8<T> a = lds_read128<T>(qb + t * 32 * kRowBytes + aoff[kk]);
+          s = mfma(a, kf[kk], s);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          vec8<T> a = lds_read128<T>(dob + t * 32 * kRowBytes + aoff[kk]);
+          dp = mfma(a, vf[kk], dp);
+        }
+        const bool need_mask = (qs0 + 32 > lq) || (p.causal && qs0 + off < kw0 + 31);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int rq = 32 * t + 8 * jj + 4 * g;      // rows rq .. rq+3 of the tile
+          const f32x4 l2v = *(__attribute__((address_space(3))) f32x4*)(st + rq * 4);
+          const f32x4 dlv = *(__attribute__((address_space(3))) f32x4*)(st + (kKvQ + rq) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * jj + e;
+            float pv = fast_exp2(__builtin_fmaf(s[r], c, -l2v[e]));
+            if (need_mask) {
+              const int q = qt0 + rq + e;
+              const bool ok = (q < lq) && (!p.causal || krow <= q + off);
+              pv = ok ? pv : 0.f;
+            }
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - dlv[e]);
+          }
+        }
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const vec8<T> pb = pack8<T>(s, 8 * ks2);
+          const vec8<T> dsb = pack8<T>(dp, 8 * ks2);
+          lds_t* dot = dob + (32 * t + 16 * ks2) * kRowBytes;
+          lds_t* qt = qb + (32 * t + 16 * ks2) * kRowBytes;
+#pragma unroll
+          for (int dblk = 0; dblk < 4; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(dot + toff[dblk][0]);
+            vec4<T> hi = lds_read_tr<T>(dot + toff[dblk][1]);
+            dv[dblk] = mfma(concat<T>(lo, hi), pb, dv[dblk]);
+          }
+#pragma unroll
+          for (int dblk = 0; dblk < 4; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(qt + toff[dblk][0]);
+            vec4<T> hi = lds_read_tr<T>(qt + toff[dblk][1]);
+            dk[dblk] = mfma(concat<T>(lo, hi), dsb, dk[dblk]);
+          }
+        }
+      }
+    }
+    if (j + 1 < jt1) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (krow >= lk) return;
+  const int64_t orow = ks.row0 + krow;
+  T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)h * p.dk_st.head;
+  T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)h * p.dv_st.head;
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int d0 = 32 * dblk + 8 * jj + 4 * g;
+      if (d0 < p.D) {
+        f32x4 x, y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          x[e] = dk[dblk][4 * jj + e] * p.scale;
+          y[e] = dv[dblk][4 * jj + e];
+        }
+        *(vec4<T>*)(dkb + d0) = __builtin_convertvector(x, vec4<T>);
+        *(vec4<T>*)(dvb + d0) = __builtin_convertvector(y, vec4<T>);
+      }
+    }
+}
+
+template <typename T>
+static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSmem);
+    attr_done = true;
+  }
+  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(dq_kernel<T>, dim3((unsigned)nblocks), dim3(kDqThreads), kDqSmem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <typename T>
+static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)dkdv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kKvSmem);
+    attr_done = true;
+  }
+  const int64_t nblocks = (int64_t)p.nkblk * p.H * p.B;
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(dkdv_kernel<T>, dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
+  return dtype == 0 ? launch_dq_t<bf16_t>(p, stream) : launch_dq_t<f16_t>(p, stream);
+}
+int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
+  return dtype == 0 ? launch_dkdv_t<bf16_t>(p, stream) : launch_dkdv_t<f16_t>(p, stream);
+}
+int bwd_dq_rows_per_block() { return kDqRows; }
+int bwd_dkdv_keys_per_block() { return kKvKeys; }
+
+}  // namespace rfa

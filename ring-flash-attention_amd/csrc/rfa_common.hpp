@@ -1,0 +1,150 @@
+// rfa_common.hpp — device-side building blocks shared by the gfx950 attention kernels.
+//
+// Conventions used by every kernel in this directory (CDNA4, wave64):
+//   * MFMA shape is v_mfma_f32_32x32x16_{bf16,f16}: D(32x32) += A(32x16) * B(16x32).
+//       A operand: lane l holds row  m = l&31, k = 8*(l>>5) .. +7   (8 x 16-bit = 4 VGPRs)
+//       B operand: lane l holds col  n = l&31, k = 8*(l>>5) .. +7
+//       C/D      : lane l, reg r holds col n = l&31, row m = (r&3) + 8*(r>>2) + 4*(l>>5)
+//     so after an MFMA a lane owns ONE column and 16 rows.  All kernels are arranged so that
+//     the softmax row (forward / dQ) or the key (dK/dV) is that column: per-row statistics
+//     are lane-local scalars and P never has to move between lanes — the k index of the
+//     second GEMM is simply *defined* as "whatever rows this lane got out of the first one":
+//        kmap(ks, g, e) = 16*ks + 8*(e>>2) + 4*g + (e&3)      (ks = 16-wide k step, g = l>>5)
+//     and the other operand is fetched from LDS with ds_read_b64_tr_b16 to match.
+//   * LDS tiles are [rows][128] 16-bit, 256 B per row, 16 chunks of 16 B, XOR-swizzled with
+//       phys_chunk = chunk ^ swz(row),  swz(row) = ((row&3)<<2) | ((row>>2)&3)
+//     which is conflict-free both for row-per-lane ds_read_b128 (16-lane groups see 16
+//     distinct 16-B slots) and for the 4-row x 64-B footprint of a transpose read.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rfa {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+template <typename T> using vec8 = T __attribute__((ext_vector_type(8)));
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+typedef __attribute__((address_space(3))) char lds_t;
+
+constexpr int kHeadDim = 128;        // compiled head dim; runtime D <= 128, D % 8 == 0 (zero padded)
+constexpr int kRowBytes = kHeadDim * 2;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 mfma(vec8<bf16_t> a, vec8<bf16_t> b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma(vec8<f16_t> a, vec8<f16_t> b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// byte offset of 16-B chunk `chunk` of row `row` inside a swizzled [rows][128] tile
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+  return row * kRowBytes + ((chunk ^ swz(row)) << 4);
+}
+
+template <typename T>
+__device__ __forceinline__ vec8<T> lds_read128(lds_t* p) {
+  return *(__attribute__((address_space(3))) vec8<T>*)p;
+}
+template <typename T>
+__device__ __forceinline__ void lds_write128(lds_t* p, vec8<T> v) {
+  *(__attribute__((address_space(3))) vec8<T>*)p = v;
+}
+
+// Transposed 4x16 read: within each 16-lane group lane i supplies the address of 4
+// contiguous 16-bit elements = row (i>>2), cols 4*(i&3)..+3 of a 4x16 block; it receives
+// column i of that block (4 elements, one per row).
+template <typename T>
+__device__ __forceinline__ vec4<T> lds_read_tr(lds_t* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(vec4<T>, r);
+}
+
+template <typename T>
+__device__ __forceinline__ vec8<T> concat(vec4<T> a, vec4<T> b) {
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// Byte offset (before the row term) that lane `lane` must use so that a transpose read at
+// rows rb..rb+3 (rb % 4 == 0, given through rsel = (rb>>2)&3) returns, for MFMA A-operand
+// lane (m = lane&31 + 32*dblk), the 4 rows rb+0..3 of column m:
+//     result[j] = tile[rb + j][32*dblk + (lane&31)]
+// Full LDS address = tile_base + (rb + (i>>2)) * 256 + tr_lane_off(lane, dblk, rsel).
+__device__ __forceinline__ int tr_lane_off(int lane, int dblk, int rsel) {
+  const int i = lane & 15;
+  const int sub = (lane >> 4) & 1;              // which 16-column half of the 32-wide block
+  const int chunk = 4 * dblk + 2 * sub + ((i & 3) >> 1);
+  const int x = ((i >> 2) << 2) | rsel;         // swz(rb + (i>>2))
+  return ((chunk ^ x) << 4) + ((i & 1) << 3);
+}
+
+// pack 8 fp32 (two groups of 4 consecutive C rows) into an MFMA 16-bit operand
+template <typename T>
+__device__ __forceinline__ vec8<T> pack8(const f32x16& s, int base) {
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  f32x8 x;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = s[base + e];
+  return __builtin_convertvector(x, vec8<T>);
+}
+
+template <typename T>
+__device__ __forceinline__ vec8<T> zero8() {
+  vec8<T> z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (T)0.0f;
+  return z;
+}
+
+// key / query index of C-layout register r for lane group g inside a 32-row block
+__device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+struct Strides {
+  int64_t batch, row, head;
+};
+
+// Resolved addressing of one (sequence, half) of a dense or packed tensor.
+struct SeqSpan {
+  int64_t row0;   // absolute first row (already includes batch offset for dense, as rows)
+  int len;        // number of rows
+};
+
+// dense: rows are [0,S) of batch b (batch offset applied through Strides::batch separately)
+// varlen: rows are [cu[b], cu[b+1])
+__device__ __forceinline__ SeqSpan resolve_span(const int32_t* cu, int b, int S, int half) {
+  int start = 0, len = S;
+  if (cu) {
+    start = cu[b];
+    len = cu[b + 1] - start;
+  }
+  if (half == 1) {
+    len = len / 2;                 // front half: [start, (start+end)/2)
+  } else if (half == 2) {
+    int mid = len / 2;             // back half:  [(start+end)/2, end)
+    start += mid;
+    len -= mid;
+  }
+  SeqSpan s;
+  s.row0 = start;
+  s.len = len;
+  return s;
+}
+
+__device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+}  // namespace rfa

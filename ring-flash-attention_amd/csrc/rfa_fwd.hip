@@ -1,0 +1,311 @@
+// rfa_fwd.hip — flash-attention forward for gfx950 (MI355X), dense + varlen, GQA, causal
+// (bottom-right aligned), optional fused online merge into fp32 (out_acc, lse_acc).
+//
+// Replaces flash_attn._flash_attn_forward / _flash_attn_varlen_forward as called from
+// /root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:52 (and siblings), and — in
+// accumulate mode — ring_flash_attn/utils.py:32-73 (update_out_and_lse).
+//
+// Structure (one workgroup = 8 waves = 256 query rows of one head; KV tile = 64 keys):
+//   * each wave owns 32 query rows; its Q fragment lives in registers for the whole kernel
+//   * K/V tiles are staged global -> registers -> LDS (issue early / write late), double
+//     buffered, one barrier per tile; LDS images are XOR-swizzled (rfa_common.hpp)
+//   * S^T = K·Q^T   (A = K rows from LDS via ds_read_b128, B = Q registers): a lane owns ONE
+//     query row (column of S^T) -> row max / row sum are in-lane, one cross-half exchange
+//   * O^T += V^T·P^T (A = V^T via ds_read_b64_tr_b16, B = P straight from the S^T registers)
+//   * epilogue: normalise, write out/lse, or merge into (out_acc, lse_acc) in fp32.
+#include "rfa_common.hpp"
+#include "rfa_kernels.hpp"
+
+namespace rfa {
+
+constexpr int kFwdWaves = 8;
+constexpr int kFwdThreads = kFwdWaves * 64;
+constexpr int kFwdQRows = kFwdWaves * 32;   // 256 query rows per workgroup
+constexpr int kFwdKV = 64;                  // keys per tile
+constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB
+constexpr int kFwdSmem = 4 * kFwdTileBytes;                 // K[2] + V[2] = 64 KiB
+
+template <typename T>
+__global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  // LDS map: K tile buffers at [0, 2*tile), V tile buffers at [2*tile, 4*tile)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  // ---- work decode: kv-head fastest so that workgroups sharing K/V sit on one XCD ----
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int gq = idx % G;
+  idx /= G;
+  const int qblk = p.nqblk - 1 - (idx % p.nqblk);   // heavy (late) causal blocks first
+  const int b = idx / p.nqblk;
+  const int h = hk * G + gq;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int qwg0 = qblk * kFwdQRows;
+  if (qwg0 >= lq) return;
+  const int off = lk - lq;                 // bottom-right causal alignment
+  const int qw0 = qwg0 + wave * 32;
+  const int qrow = qw0 + l31;
+  const int qrow_c = qrow < lq ? qrow : lq - 1;
+
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+
+  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + (qs.row0 + qrow_c) * p.q_st.row +
+                   (int64_t)h * p.q_st.head;
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row +
+                   (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row +
+                   (int64_t)hk * p.v_st.head;
+
+  // ---- Q fragment (B operand of S^T = K Q^T): lane (q = l31, g) holds d = 16kk + 8g .. +7
+  vec8<T> qf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int d0 = 16 * kk + 8 * g;
+    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+  }
+
+  // ---- KV range of this workgroup
+  const int qend = (qwg0 + kFwdQRows < lq) ? qwg0 + kFwdQRows : lq;
+  int kmax = lk;
+  if (p.causal && qend + off < kmax) kmax = qend + off;
+  const int ntiles = kmax > 0 ? (kmax + kFwdKV - 1) / kFwdKV : 0;
+
+  // ---- staging assignment: thread -> chunk c of rows r0, r0+32
+  const int sc = tid & 15;
+  const int sr = tid >> 4;
+  const bool sd_ok = sc * 8 < p.D;
+  vec8<T> kreg[2], vreg[2];
+
+  auto load_tile = [&](int j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int kr = j * kFwdKV + sr + 32 * i;
+      kr = kr < lk ? kr : lk - 1;
+      if (sd_ok) {
+        kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
+        vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
+      } else {
+        kreg[i] = zero8<T>();
+        vreg[i] = zero8<T>();
+      }
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = sr + 32 * i;
+      const int o = tile_off(row, sc);
+      lds_write128<T>(smem + buf * kFwdTileBytes + o, kreg[i]);
+      lds_write128<T>(smem + (2 + buf) * kFwdTileBytes + o, vreg[i]);
+    }
+  };
+
+  // ---- per-lane LDS offsets
+  // K fragment (A operand): row = 32t + l31, chunk = 2kk + g
+  int koff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) koff[kk] = tile_off(l31, 2 * kk + g);   // + t*32*256
+  // V^T fragment via transpose read: rows rb = 32t + 16ks + 8hh + 4g (+ i>>2)
+  int voff[4][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+      voff[dblk][hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
+                       tr_lane_off(lane, dblk, (2 * hh + g) & 3);
+
+  const float c = p.scale * kLog2e;
+  float m = -INFINITY;
+  float lsum = 0.f;
+  f32x16 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+  if (ntiles > 0) {
+    load_tile(0);
+    write_tile(0);
+  }
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int buf = j & 1;
+    lds_t* kb = smem + buf * kFwdTileBytes;
+    lds_t* vtile = smem + (2 + buf) * kFwdTileBytes;
+    if (j + 1 < ntiles) load_tile(j + 1);
+
+    const int kt0 = j * kFwdKV;
+    const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
+    if (active) {
+      // ---------------- S^T = K Q^T ----------------
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          vec8<T> a = lds_read128<T>(kb + t * 32 * kRowBytes + koff[kk]);
+          s[t] = mfma(a, qf[kk], s[t]);
+        }
+      }
+      // ---------------- mask ----------------
+      const bool need_mask = (kt0 + kFwdKV > lk) || (p.causal && kt0 + kFwdKV - 1 > qw0 + off);
+      if (need_mask) {
+        const int lim = p.causal ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt0 + 32 * t + crow(r, g);
+            if (key > lim) s[t][r] = -INFINITY;
+          }
+      }
+      // ---------------- online softmax ----------------
+      float mloc = s[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+      mloc = fmaxf(mloc, shfl_xor32(mloc));
+      const float mnew = fmaxf(m, mloc);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float alpha = fast_exp2(m * c - msafe * c);
+      m = mnew;
+      const float mc = msafe * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(__builtin_fmaf(s[t][r], c, -mc));
+          s[t][r] = pv;
+          psum += pv;
+        }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+      // ---------------- O^T += V^T P^T ----------------
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const vec8<T> pb = pack8<T>(s[t], 8 * ks2);
+          lds_t* vb = vtile + (32 * t + 16 * ks2) * kRowBytes;
+#pragma unroll
+          for (int dblk = 0; dblk < 4; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(vb + voff[dblk][0]);
+            vec4<T> hi = lds_read_tr<T>(vb + voff[dblk][1]);
+            o[dblk] = mfma(concat<T>(lo, hi), pb, o[dblk]);
+          }
+        }
+    }
+    if (j + 1 < ntiles) write_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  if (qrow >= lq) return;
+  const float l = lsum + shfl_xor32(lsum);
+  const bool has = l > 0.f;
+  const float inv = has ? 1.f / l : 0.f;
+  const float blse = has ? m * p.scale + __logf(l) : INFINITY;   // natural log
+  const int64_t orow = qs.row0 + qrow;
+
+  if (p.out_acc == nullptr) {
+    T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (d0 < p.D) {
+          f32x4 x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
+          *(vec4<T>*)(ob + d0) = __builtin_convertvector(x, vec4<T>);
+        }
+      }
+    if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
+  } else {
+    float* ab = p.out_acc + qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row +
+                (int64_t)h * p.out_acc_st.head;
+    float* lp = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
+    if (p.acc_init) {
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
+            *(f32x4*)(ab + d0) = x;
+          }
+        }
+      if (g == 0) *lp = has ? blse : -INFINITY;
+    } else if (has) {
+      // merge (out_old, lse_old) with (O/l, blse):  lse' = logaddexp, weights exp(x - lse')
+      const float lold = *lp;
+      const float mx = fmaxf(lold, blse);
+      const float eo = __expf(lold - mx);      // lold = -inf -> 0
+      const float eb = __expf(blse - mx);
+      const float den = eo + eb;
+      const float wo = eo / den;
+      const float wb = eb / den * inv;
+      const float lnew = mx + __logf(den);
+#pragma unroll
+      for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x = *(f32x4*)(ab + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] * wo + o[dblk][4 * jj + e] * wb;
+            *(f32x4*)(ab + d0) = x;
+          }
+        }
+      if (g == 0) *lp = lnew;   // both half-lanes read *lp earlier in program order
+    }
+  }
+}
+
+template <typename T>
+static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kFwdSmem);
+    attr_done = true;
+  }
+  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(fwd_kernel<T>, dim3((unsigned)nblocks), dim3(kFwdThreads), kFwdSmem, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
+  return dtype == 0 ? launch_fwd_t<bf16_t>(p, stream) : launch_fwd_t<f16_t>(p, stream);
+}
+
+int fwd_qrows_per_block() { return kFwdQRows; }
+
+}  // namespace rfa

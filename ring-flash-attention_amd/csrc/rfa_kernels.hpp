@@ -1,0 +1,85 @@
+// rfa_kernels.hpp — host-visible parameter blocks and launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rfa_common.hpp"
+
+namespace rfa {
+
+struct FwdParams {
+  const void *q, *k, *v;
+  void* out;
+  float* lse;
+  float* out_acc;
+  float* lse_acc;
+  const int32_t *cu_q, *cu_k;
+  Strides q_st, k_st, v_st, out_st, out_acc_st;
+  int64_t lse_batch, lse_head, lse_acc_batch, lse_acc_head;
+  int B, H, Hk, D, Sq, Sk;
+  int q_half, k_half;
+  int causal, acc_init;
+  int nqblk;
+  float scale;
+};
+
+struct PreParams {
+  const void *dout, *out;
+  float* delta;
+  const int32_t* cu_q;
+  Strides dout_st, out_st;
+  int64_t delta_batch, delta_head;
+  int B, H, D, Sq, q_half;
+};
+
+struct BwdParams {
+  const void *dout, *q, *k, *v;
+  const float *lse, *delta;
+  void *dq;            // io dtype (or nullptr when dq_acc)
+  float* dq_acc;
+  void *dk, *dv;       // per-q-head outputs, io dtype: head index = q head
+  const int32_t *cu_q, *cu_k;
+  Strides dout_st, q_st, k_st, v_st, dq_st, dq_acc_st, dk_st, dv_st;
+  int64_t lse_batch, lse_head, delta_batch, delta_head;
+  int B, H, Hk, D, Sq, Sk;
+  int q_half, k_half;
+  int causal, acc_init;
+  int nqblk, nkblk;
+  float scale;
+};
+
+// dst[b, row, hk, :] (=|+=) sum_g src[b, row, hk*G+g, :]
+struct ReduceParams {
+  const void* src;     // io dtype partials, head index = q head
+  void* dst;           // io dtype (or nullptr)
+  float* dst_acc;      // fp32 accumulate target (or nullptr)
+  const int32_t* cu_k;
+  Strides src_st, dst_st, dst_acc_st;
+  int B, Hk, G, D, Sk, k_half, acc_init;
+};
+
+struct MergeParams {
+  float* out_acc;
+  float* lse_acc;
+  const void* block_out;
+  const float* block_lse;
+  Strides out_acc_st, block_out_st;
+  int64_t lse_acc_batch, lse_acc_head, block_lse_batch, block_lse_head;
+  int B, H, D, S, acc_init;
+};
+
+int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream);
+int fwd_qrows_per_block();
+
+int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream);
+int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream);
+int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream);
+int bwd_dq_rows_per_block();
+int bwd_dkdv_keys_per_block();
+int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);
+int launch_merge(const MergeParams& p, int dtype, hipStream_t stream);
+int launch_cast(void* dst, const float* src, int64_t n, int dtype, hipStream_t stream);
+int launch_lse_relayout(float* dst, const float* src, const int32_t* cu, int B, int H,
+                        int max_seqlen, int64_t packed_head_stride, int64_t packed_row_stride,
+                        bool flatten, hipStream_t stream);
+
+}  // namespace rfa
