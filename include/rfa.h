@@ -142,7 +142,15 @@ typedef struct {
   int32_t causal;
   int32_t deterministic; /* accepted; this implementation is always deterministic */
   int32_t dtype;
+  /* 0 = everything.  RFA_BWD_COMPUTE: dQ + per-head dK/dV partials into `workspace` only;
+   * RFA_BWD_REDUCE: group-sum the partials of a previous COMPUTE call into dk/dv or
+   * dk_acc/dv_acc.  Splitting lets a ring step overlap the compute with the arrival of the
+   * dk/dv accumulators it will add into (zigzag_ring_flash_attn.py:172-187).  With phases != 0
+   * the workspace is always required. */
+  int32_t phases;
 } rfa_bwd_args;
+
+enum { RFA_BWD_ALL = 0, RFA_BWD_COMPUTE = 1, RFA_BWD_REDUCE = 2 };
 
 typedef struct {
   float *out_acc;          /* (B,S,H,D) fp32, updated in place */
@@ -156,6 +164,9 @@ typedef struct {
   int32_t B, H, D, S;      /* S rows are merged (pass slice pointers for a row range) */
   int32_t acc_init;
   int32_t dtype;
+  /* element stride between consecutive rows of lse_acc / block_lse; 0 means 1.  The
+   * reference keeps its running lse as (B,S,H,1) (utils.py:41,64): batch=S*H, head=1, row=H. */
+  int64_t lse_acc_row, block_lse_row;
 } rfa_merge_args;
 
 int rfa_abi_version(void);

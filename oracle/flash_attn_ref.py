@@ -1,0 +1,282 @@
+"""oracle/flash_attn_ref.py — TEST INFRASTRUCTURE ONLY (parity oracle; never the product path).
+
+CPU restatement, in plain PyTorch, of the four private entry points of the third-party package
+that the reference delegates all arithmetic to and which is absent from /root/reference:
+
+    flash_attn.flash_attn_interface._flash_attn_forward          (used at zigzag_ring_flash_attn.py:52,
+                                                                  ring_flash_attn.py:53)
+    flash_attn.flash_attn_interface._flash_attn_backward         (zigzag_ring_flash_attn.py:156,
+                                                                  ring_flash_attn.py:131)
+    flash_attn.flash_attn_interface._flash_attn_varlen_forward   (ring_flash_attn_varlen.py:77,
+                                                                  zigzag_ring_flash_attn_varlen.py:137,
+                                                                  llama3_flash_attn_varlen.py:147)
+    flash_attn.flash_attn_interface._flash_attn_varlen_backward  (ring_flash_attn_varlen.py:169,
+                                                                  zigzag_ring_flash_attn_varlen.py:275,
+                                                                  llama3_flash_attn_varlen.py:282)
+
+Dependency: PyPI `flash-attn` (Dao-AILab/flash-attention).  The reference pins no version
+(pyproject.toml:1-22); its call sites select behaviour by introspection (utils.py:13-29) and
+support both the <2.7 and >=2.7 calling conventions.  This file restates the **>= 2.7**
+convention: keyword `window_size_left/right`, 4-tuple forward return
+`(out, softmax_lse, S_dmask, rng_state)`, packed `(nheads, total)` varlen LSE, bottom-right
+aligned causal mask, rows without any visible key -> out 0 / lse +inf, in-place dq/dk/dv.
+
+Published algorithm restated (FlashAttention-2, Dao 2023, Alg. 1/2), computed exactly (no
+tiling — tiling does not change the mathematical result), fp32 math on the given inputs:
+    S = scale * Q K^T (+mask)      lse = logsumexp(S)      O = softmax(S) V
+    P = exp(S - lse)   D = rowsum(dO * O)   dP = dO V^T   dS = P * (dP - D)
+    dQ = scale dS K    dK = scale dS^T Q    dV = P^T dO    (dK,dV summed over a GQA group)
+Outputs are rounded to the input dtype exactly where flash_attn rounds (out, dq, dk, dv).
+
+PARITY PINNING: the reference's own tests hold no numeric golden vectors for this boundary
+(test/utils.py:15-38 only prints diffs), so it is "parity unpinned" against flash_attn itself.
+It is pinned instead (tests/test_oracle.py) against an independent fp64 softmax-attention
+with torch autograd, and against the C restatement oracle/attn_ref.c.
+"""
+import math
+from typing import Optional
+
+import torch
+
+__all__ = [
+    "_flash_attn_forward",
+    "_flash_attn_backward",
+    "_flash_attn_varlen_forward",
+    "_flash_attn_varlen_backward",
+]
+
+_CHUNK = 1024  # query rows per score block (bounds memory, not a numerical choice)
+
+
+def _mask(sq0: int, nq: int, lq: int, lk: int, causal: bool, device):
+    """bool (nq, lk): True where key j is visible to query row sq0+i (bottom-right aligned)."""
+    if not causal:
+        return None
+    qi = torch.arange(sq0, sq0 + nq, device=device).unsqueeze(1)
+    kj = torch.arange(lk, device=device).unsqueeze(0)
+    return kj <= qi + (lk - lq)
+
+
+def _fwd_one(q, k, v, scale, causal):
+    """q (Lq,H,D), k,v (Lk,Hk,D) -> out fp32 (Lq,H,D), lse fp32 (H,Lq)."""
+    Lq, H, D = q.shape
+    Lk, Hk, _ = k.shape
+    G = H // Hk
+    qf = q.float().permute(1, 0, 2)                       # (H,Lq,D)
+    kf = k.float().permute(1, 0, 2).repeat_interleave(G, dim=0)   # (H,Lk,D)
+    vf = v.float().permute(1, 0, 2).repeat_interleave(G, dim=0)
+    out = torch.zeros((H, Lq, D), dtype=torch.float32, device=q.device)
+    lse = torch.full((H, Lq), float("inf"), dtype=torch.float32, device=q.device)
+    if Lk == 0:
+        return out.permute(1, 0, 2), lse
+    for s0 in range(0, Lq, _CHUNK):
+        n = min(_CHUNK, Lq - s0)
+        s = torch.matmul(qf[:, s0:s0 + n], kf.transpose(1, 2)) * scale        # (H,n,Lk)
+        m = _mask(s0, n, Lq, Lk, causal, q.device)
+        if m is not None:
+            s = s.masked_fill(~m, float("-inf"))
+        l = torch.logsumexp(s, dim=-1)                                         # -inf for empty rows
+        p = torch.exp(s - l.unsqueeze(-1))
+        empty = torch.isinf(l) & (l < 0)
+        p = torch.where(empty.unsqueeze(-1), torch.zeros_like(p), p)
+        out[:, s0:s0 + n] = torch.matmul(p, vf)
+        lse[:, s0:s0 + n] = torch.where(empty, torch.full_like(l, float("inf")), l)
+    return out.permute(1, 0, 2), lse
+
+
+def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None):
+    """returns fp32 dq (Lq,H,D), dk, dv (Lk,Hk,D).  lse (H,Lq); delta (H,Lq) overrides rowsum(dO*O)."""
+    Lq, H, D = q.shape
+    Lk, Hk, _ = k.shape
+    G = H // Hk
+    qf = q.float().permute(1, 0, 2)
+    dof = dout.float().permute(1, 0, 2)
+    kf = k.float().permute(1, 0, 2).repeat_interleave(G, dim=0)
+    vf = v.float().permute(1, 0, 2).repeat_interleave(G, dim=0)
+    if delta is None:
+        delta = (dof * out.float().permute(1, 0, 2)).sum(-1)                    # (H,Lq)
+    dq = torch.zeros((H, Lq, D), dtype=torch.float32, device=q.device)
+    dk = torch.zeros((H, Lk, D), dtype=torch.float32, device=q.device)
+    dv = torch.zeros((H, Lk, D), dtype=torch.float32, device=q.device)
+    if Lk > 0:
+        for s0 in range(0, Lq, _CHUNK):
+            n = min(_CHUNK, Lq - s0)
+            s = torch.matmul(qf[:, s0:s0 + n], kf.transpose(1, 2)) * scale
+            p = torch.exp(s - lse[:, s0:s0 + n].unsqueeze(-1))
+            m = _mask(s0, n, Lq, Lk, causal, q.device)
+            if m is not None:
+                p = torch.where(m, p, torch.zeros_like(p))
+            dp = torch.matmul(dof[:, s0:s0 + n], vf.transpose(1, 2))
+            ds = p * (dp - delta[:, s0:s0 + n].unsqueeze(-1)) * scale
+            dq[:, s0:s0 + n] = torch.matmul(ds, kf)
+            dk += torch.matmul(ds.transpose(1, 2), qf[:, s0:s0 + n])
+            dv += torch.matmul(p.transpose(1, 2), dof[:, s0:s0 + n])
+    dk = dk.view(Hk, G, Lk, D).sum(1)
+    dv = dv.view(Hk, G, Lk, D).sum(1)
+    return dq.permute(1, 0, 2), dk.permute(1, 0, 2), dv.permute(1, 0, 2)
+
+
+def _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes):
+    assert not dropout_p, "oracle: dropout is not restated (the reference path uses dropout_p=0)"
+    assert window_size_left in (-1, None) and window_size_right in (-1, 0, None), "oracle: no sliding window"
+    assert not softcap, "oracle: softcap not restated"
+    assert alibi_slopes is None, "oracle: alibi not restated"
+
+
+def _flash_attn_forward(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    dropout_p: float,
+    softmax_scale: float,
+    causal: bool,
+    window_size_left: int = -1,
+    window_size_right: int = -1,
+    softcap: float = 0.0,
+    alibi_slopes: Optional[torch.Tensor] = None,
+    return_softmax: bool = False,
+):
+    """q (B,Sq,H,D), k/v (B,Sk,Hk,D) -> (out (B,Sq,H,D) q.dtype, lse (B,H,Sq) fp32, None, None)."""
+    _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
+    B = q.shape[0]
+    outs, lses = [], []
+    for b in range(B):
+        o, l = _fwd_one(q[b], k[b], v[b], softmax_scale, causal)
+        outs.append(o)
+        lses.append(l)
+    out = torch.stack(outs).to(q.dtype)
+    lse = torch.stack(lses)
+    return out, lse, None, None
+
+
+def _flash_attn_backward(
+    dout: torch.Tensor,
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    out: torch.Tensor,
+    softmax_lse: torch.Tensor,
+    dq: Optional[torch.Tensor],
+    dk: Optional[torch.Tensor],
+    dv: Optional[torch.Tensor],
+    dropout_p: float,
+    softmax_scale: float,
+    causal: bool,
+    window_size_left: int = -1,
+    window_size_right: int = -1,
+    softcap: float = 0.0,
+    alibi_slopes: Optional[torch.Tensor] = None,
+    deterministic: bool = False,
+    rng_state: Optional[torch.Tensor] = None,
+):
+    """Writes dq/dk/dv IN PLACE (views allowed, as the reference passes `dq_buffer[:, :seqlen_q]`,
+    zigzag_ring_flash_attn.py:137-139).  Returns softmax_d (B,H,Sq)."""
+    _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
+    B = q.shape[0]
+    ds = []
+    for b in range(B):
+        gq, gk, gv = _bwd_one(dout[b], q[b], k[b], v[b], out[b], softmax_lse[b], softmax_scale, causal)
+        dq[b].copy_(gq.to(dq.dtype))
+        dk[b].copy_(gk.to(dk.dtype))
+        dv[b].copy_(gv.to(dv.dtype))
+        ds.append((dout[b].float() * out[b].float()).sum(-1).transpose(0, 1))
+    return torch.stack(ds)
+
+
+def _flash_attn_varlen_forward(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    cu_seqlens_q: torch.Tensor,
+    cu_seqlens_k: torch.Tensor,
+    max_seqlen_q: int,
+    max_seqlen_k: int,
+    dropout_p: float,
+    softmax_scale: float,
+    causal: bool,
+    window_size_left: int = -1,
+    window_size_right: int = -1,
+    softcap: float = 0.0,
+    alibi_slopes: Optional[torch.Tensor] = None,
+    return_softmax: bool = False,
+    block_table: Optional[torch.Tensor] = None,
+    leftpad_k: Optional[torch.Tensor] = None,
+    seqused_k: Optional[torch.Tensor] = None,
+    zero_tensors: bool = False,
+):
+    """q (Tq,H,D), k/v (Tk,Hk,D) -> (out (Tq,H,D), lse (H,Tq) fp32, None, None)."""
+    _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
+    assert block_table is None and leftpad_k is None and seqused_k is None
+    Tq, H, D = q.shape
+    out = torch.zeros((Tq, H, D), dtype=torch.float32, device=q.device)
+    lse = torch.zeros((H, Tq), dtype=torch.float32, device=q.device)
+    cq = [int(x) for x in cu_seqlens_q.tolist()]
+    ck = [int(x) for x in cu_seqlens_k.tolist()]
+    for i in range(len(cq) - 1):
+        o, l = _fwd_one(q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]], softmax_scale, causal)
+        out[cq[i]:cq[i + 1]] = o
+        lse[:, cq[i]:cq[i + 1]] = l
+    return out.to(q.dtype), lse, None, None
+
+
+def _flash_attn_varlen_backward(
+    dout: torch.Tensor,
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    out: torch.Tensor,
+    softmax_lse: torch.Tensor,
+    dq: Optional[torch.Tensor],
+    dk: Optional[torch.Tensor],
+    dv: Optional[torch.Tensor],
+    cu_seqlens_q: torch.Tensor,
+    cu_seqlens_k: torch.Tensor,
+    max_seqlen_q: int,
+    max_seqlen_k: int,
+    dropout_p: float,
+    softmax_scale: float,
+    causal: bool,
+    window_size_left: int = -1,
+    window_size_right: int = -1,
+    softcap: float = 0.0,
+    alibi_slopes: Optional[torch.Tensor] = None,
+    deterministic: bool = False,
+    rng_state: Optional[torch.Tensor] = None,
+    zero_tensors: bool = False,
+):
+    _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
+    cq = [int(x) for x in cu_seqlens_q.tolist()]
+    ck = [int(x) for x in cu_seqlens_k.tolist()]
+    for i in range(len(cq) - 1):
+        a, b = cq[i], cq[i + 1]
+        c, d = ck[i], ck[i + 1]
+        gq, gk, gv = _bwd_one(dout[a:b], q[a:b], k[c:d], v[c:d], out[a:b], softmax_lse[:, a:b], softmax_scale, causal)
+        dq[a:b] = gq.to(dq.dtype)
+        dk[c:d] = gk.to(dk.dtype)
+        dv[c:d] = gv.to(dv.dtype)
+    return (dout.float() * out.float()).sum(-1).transpose(0, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# Public single-device functions the reference TESTS use as ground truth
+# (`from flash_attn import flash_attn_qkvpacked_func, ...`, test/test_zigzag_ring_flash_attn_func.py:2).
+# Independent formulation: plain softmax attention in fp64 with torch autograd.
+# --------------------------------------------------------------------------------------------
+def full_attention_fp64(q, k, v, causal, softmax_scale=None):
+    """q (B,Sq,H,D) k/v (B,Sk,Hk,D) any float dtype -> out fp64 (B,Sq,H,D), lse fp64 (B,H,Sq).
+    Differentiable (autograd) — the independent reference the oracle itself is pinned to."""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
+    qd = q.double().permute(0, 2, 1, 3)
+    kd = k.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
+    vd = v.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
+    s = torch.matmul(qd, kd.transpose(-1, -2)) * scale
+    if causal:
+        m = _mask(0, Sq, Sq, Sk, True, q.device)
+        s = s.masked_fill(~m, float("-inf"))
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.softmax(s, dim=-1)
+    p = torch.nan_to_num(p, nan=0.0)
+    out = torch.matmul(p, vd).permute(0, 2, 1, 3)
+    return out, lse

@@ -106,7 +106,9 @@ int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {
   return launch_preprocess(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
 }
 
-static bool bwd_needs_ws(const rfa_bwd_args* a) { return a->H != a->Hk || a->dk_acc != nullptr; }
+static bool bwd_needs_ws(const rfa_bwd_args* a) {
+  return a->H != a->Hk || a->dk_acc != nullptr || a->phases != RFA_BWD_ALL;
+}
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
@@ -166,9 +168,13 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
   }
-  if (launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
-  if (launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
-  if (ws) {
+  const bool do_compute = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_COMPUTE);
+  const bool do_reduce = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_REDUCE);
+  if (do_compute) {
+    if (launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+    if (launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+  }
+  if (ws && do_reduce) {
     for (int which = 0; which < 2; ++which) {
       ReduceParams r{};
       r.src = which ? p.dv : p.dk;
@@ -204,6 +210,8 @@ int rfa_merge(const rfa_merge_args* a, void* stream) {
   p.out_acc_st = cv(a->out_acc_st); p.block_out_st = cv(a->block_out_st);
   p.lse_acc_batch = a->lse_acc_batch; p.lse_acc_head = a->lse_acc_head;
   p.block_lse_batch = a->block_lse_batch; p.block_lse_head = a->block_lse_head;
+  p.lse_acc_row = a->lse_acc_row ? a->lse_acc_row : 1;
+  p.block_lse_row = a->block_lse_row ? a->block_lse_row : 1;
   p.B = a->B; p.H = a->H; p.D = a->D; p.S = a->S; p.acc_init = a->acc_init ? 1 : 0;
   return launch_merge(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
 }

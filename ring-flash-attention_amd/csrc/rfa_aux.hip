@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeParams p) {
   const int row = (int)(item / p.H);
   const int h = (int)(item % p.H);
   if (row >= p.S) return;
-  float* lp = p.lse_acc + (int64_t)b * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + row;
-  const float blse = p.block_lse[(int64_t)b * p.block_lse_batch + (int64_t)h * p.block_lse_head + row];
+  float* lp = p.lse_acc + (int64_t)b * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + row * p.lse_acc_row;
+  const float blse = p.block_lse[(int64_t)b * p.block_lse_batch + (int64_t)h * p.block_lse_head +
+                                 row * p.block_lse_row];
   float wo, wb, lnew;
   if (p.acc_init) {
     wo = 0.f; wb = 1.f; lnew = blse;

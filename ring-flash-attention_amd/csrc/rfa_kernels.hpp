@@ -64,6 +64,7 @@ struct MergeParams {
   const float* block_lse;
   Strides out_acc_st, block_out_st;
   int64_t lse_acc_batch, lse_acc_head, block_lse_batch, block_lse_head;
+  int64_t lse_acc_row, block_lse_row;
   int B, H, D, S, acc_init;
 };
 

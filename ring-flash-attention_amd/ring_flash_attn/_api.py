@@ -1,0 +1,117 @@
+"""Public-API factory: one autograd Function + the (func, kvpacked_func, qkvpacked_func)
+trio per algorithm, generated from its `*_forward` / `*_backward` schedule.
+
+The generated callables keep the exact keyword surface of the reference package
+(/root/reference/ring_flash_attn/__init__.py:1-35 and SURVEY.md Appendix A):
+    dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+    deterministic=False, return_attn_probs=False, group=None
+with the reference's semantics: softmax_scale None -> head_dim ** -0.5; alibi_slopes must be
+None; dropout_p / window_size are accepted but unsupported (reference README.md:158-159);
+return_attn_probs=True -> (out, softmax_lse, None); `group=None` is the default process group;
+inputs are the caller's LOCAL shard.
+"""
+import torch
+
+from ._common import _prep_qkv, _as_cu
+
+
+def _check_unsupported(dropout_p, window_size, alibi_slopes):
+    assert alibi_slopes is None
+    if dropout_p and dropout_p > 0:
+        raise NotImplementedError("ring_flash_attn: dropout is not supported (as in the reference)")
+    if tuple(window_size) != (-1, -1):
+        raise NotImplementedError("ring_flash_attn: sliding window is not supported (as in the reference)")
+
+
+def make_autograd_function(name, forward_impl, backward_impl, n_lead):
+    """n_lead: number of non-tensor positional arguments between (q,k,v) and the common tail
+    (0 for the batch API, 2 = (cu_seqlens, max_seqlen) for varlen)."""
+
+    class _Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, q, k, v, *rest):
+            lead = rest[:n_lead]
+            (dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic,
+             return_softmax, group) = rest[n_lead:]
+            if softmax_scale is None:
+                softmax_scale = q.shape[-1] ** (-0.5)
+            _check_unsupported(dropout_p, window_size, alibi_slopes)
+            q, k, v = _prep_qkv(q, k, v, group)
+            tensors_lead = ()
+            if n_lead:
+                cu = _as_cu(lead[0], q.device)
+                lead = (cu,) + tuple(lead[1:])
+                tensors_lead = (cu,)
+            out, softmax_lse = forward_impl(
+                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+            )
+            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
+            ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.deterministic = deterministic
+            ctx.group = group
+            return out if not return_softmax else (out, softmax_lse, None)
+
+        @staticmethod
+        def backward(ctx, dout, *args):
+            q, k, v, out, softmax_lse, *tensors_lead = ctx.saved_tensors
+            dq, dk, dv = backward_impl(
+                ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
+                softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
+                window_size=(-1, -1), alibi_slopes=None, deterministic=ctx.deterministic,
+            )
+            return (dq, dk, dv) + (None,) * (n_lead + 8)
+
+    _Fn.__name__ = _Fn.__qualname__ = name
+    return _Fn
+
+
+def make_dense_api(fn, prefix):
+    """(B,S,H,D) API: returns (func, kvpacked_func, qkvpacked_func)."""
+
+    def func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+             alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        return fn.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
+                        deterministic, return_attn_probs, group)
+
+    def kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                      alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        return fn.apply(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size,
+                        alibi_slopes, deterministic, return_attn_probs, group)
+
+    def qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                       alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        return fn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal,
+                        window_size, alibi_slopes, deterministic, return_attn_probs, group)
+
+    for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
+        f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
+    return func, kvpacked_func, qkvpacked_func
+
+
+def make_varlen_api(fn, prefix):
+    """(T,H,D) + (cu_seqlens, max_seqlen) API."""
+
+    def func(q, k, v, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+             window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False,
+             group=None):
+        return fn.apply(q, k, v, cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal, window_size,
+                        alibi_slopes, deterministic, return_attn_probs, group)
+
+    def kvpacked_func(q, kv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                      window_size=(-1, -1), alibi_slopes=None, deterministic=False,
+                      return_attn_probs=False, group=None):
+        return fn.apply(q, kv[:, 0], kv[:, 1], cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal,
+                        window_size, alibi_slopes, deterministic, return_attn_probs, group)
+
+    def qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                       window_size=(-1, -1), alibi_slopes=None, deterministic=False,
+                       return_attn_probs=False, group=None):
+        return fn.apply(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, max_seqlen, dropout_p, softmax_scale,
+                        causal, window_size, alibi_slopes, deterministic, return_attn_probs, group)
+
+    for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
+        f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
+    return func, kvpacked_func, qkvpacked_func

@@ -1,0 +1,266 @@
+"""Operator backend: the seam between the ring schedules (Python) and the attention kernels.
+
+`HipBackend` is the product: it translates torch tensors into the plain-pointer C ABI of
+librfa_hip.so (include/rfa.h) and launches on torch's current HIP stream.  It is the stand-in
+for what the reference imports from the CUDA-only `flash_attn` package
+(/root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:3, ring_flash_attn_varlen.py:3-6).
+
+There is deliberately NO CPU implementation here.  `set_backend()` exists so that the test
+suite can inject the CPU oracle (oracle/flash_attn_ref.py) to exercise the *schedules* under
+gloo on a GPU-less machine; the product never selects anything but HipBackend, and HipBackend
+raises if the extension is missing or a tensor is not on a HIP device.
+"""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _C
+
+HALF_FULL, HALF_FRONT, HALF_BACK = _C.HALF_FULL, _C.HALF_FRONT, _C.HALF_BACK
+
+_DTYPES = {torch.bfloat16: _C.RFA_BF16, torch.float16: _C.RFA_F16}
+
+
+def _st3(t: torch.Tensor, varlen: bool) -> _C.Strides:
+    """(batch,row,head) element strides of (B,S,H,D) or (T,H,D)."""
+    if t.stride(-1) != 1:
+        raise ValueError("last (head_dim) stride must be 1")
+    if varlen:
+        return _C.Strides(0, t.stride(0), t.stride(1))
+    return _C.Strides(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _lse_st(t: torch.Tensor, varlen: bool):
+    """(batch, head) strides of a (B,H,S) / (H,T) fp32 tensor; row stride must be 1."""
+    if t.dtype != torch.float32:
+        raise ValueError("lse/delta tensors must be float32")
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise ValueError("lse row stride must be 1")
+    if varlen:
+        return 0, t.stride(0)
+    return t.stride(0), t.stride(1)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class HipBackend:
+    """MI355X kernels through the C ABI.  All methods enqueue on the current stream and return
+    immediately; outputs are caller-allocated unless stated otherwise."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _C.load()
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _check_dev(*ts):
+        for t in ts:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError(
+                    "ring_flash_attn: tensors must live on a HIP (cuda) device — there is no CPU "
+                    "compute path in this package"
+                )
+
+    @staticmethod
+    def _dtype(t):
+        try:
+            return _DTYPES[t.dtype]
+        except KeyError:
+            raise TypeError(f"ring_flash_attn: unsupported dtype {t.dtype} (bf16/fp16 only)") from None
+
+    def _workspace(self, device, nbytes):
+        """Per-device grow-only scratch for the per-q-head dK/dV partials (caller-owned memory
+        from torch's caching allocator; the C library itself never allocates)."""
+        key = (device.type, device.index)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+        return buf
+
+    # ------------------------------------------------------------------ forward
+    def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
+            max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL, k_half=HALF_FULL,
+            out=None, lse=None, out_acc=None, lse_acc=None, acc_init=False):
+        """Block attention.  Plain mode fills (out, lse); accumulate mode merges into the fp32
+        (out_acc, lse_acc) pair (fused update_out_and_lse).  Dense: q (B,Sq,H,D); varlen: (T,H,D)."""
+        self._check_dev(q, k, v, out, lse, out_acc, lse_acc)
+        varlen = cu_seqlens_q is not None
+        a = _C.FwdArgs()
+        a.q, a.k, a.v = _ptr(q), _ptr(k), _ptr(v)
+        a.q_st, a.k_st, a.v_st = _st3(q, varlen), _st3(k, varlen), _st3(v, varlen)
+        if out_acc is not None:
+            a.out_acc, a.out_acc_st = _ptr(out_acc), _st3(out_acc, varlen)
+            a.lse_acc = _ptr(lse_acc)
+            a.lse_acc_batch, a.lse_acc_head = _lse_st(lse_acc, varlen)
+            a.acc_init = 1 if acc_init else 0
+        else:
+            a.out, a.out_st = _ptr(out), _st3(out, varlen)
+            a.lse = _ptr(lse)
+            a.lse_batch, a.lse_head = _lse_st(lse, varlen)
+        if varlen:
+            a.cu_seqlens_q, a.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+            a.B = cu_seqlens_q.numel() - 1
+            a.H, a.D = q.shape[1], q.shape[2]
+            a.Hk = k.shape[1]
+            a.Sq, a.Sk = int(max_seqlen_q), int(max_seqlen_k)
+        else:
+            a.B, a.Sq, a.H, a.D = q.shape
+            a.Sk, a.Hk = k.shape[1], k.shape[2]
+        a.q_half, a.k_half = q_half, k_half
+        a.softmax_scale = float(softmax_scale)
+        a.causal = 1 if causal else 0
+        a.dtype = self._dtype(q)
+        _C.check(self.lib.rfa_fwd(C.byref(a), _stream(q)), "rfa_fwd")
+
+    # ------------------------------------------------------------------ backward
+    def bwd_preprocess(self, dout, out, delta, *, cu_seqlens_q=None, max_seqlen_q=None, q_half=HALF_FULL):
+        """delta[b,h,i] = sum_d dout*out, fp32, laid out like lse."""
+        self._check_dev(dout, out, delta)
+        varlen = cu_seqlens_q is not None
+        a = _C.BwdPreArgs()
+        a.dout, a.out, a.delta = _ptr(dout), _ptr(out), _ptr(delta)
+        a.dout_st, a.out_st = _st3(dout, varlen), _st3(out, varlen)
+        a.delta_batch, a.delta_head = _lse_st(delta, varlen)
+        if varlen:
+            a.cu_seqlens_q = _ptr(cu_seqlens_q)
+            a.B = cu_seqlens_q.numel() - 1
+            a.H, a.D = dout.shape[1], dout.shape[2]
+            a.Sq = int(max_seqlen_q)
+        else:
+            a.B, a.Sq, a.H, a.D = dout.shape
+        a.q_half = q_half
+        a.dtype = self._dtype(dout)
+        _C.check(self.lib.rfa_bwd_preprocess(C.byref(a), _stream(dout)), "rfa_bwd_preprocess")
+
+    def bwd(self, dout, q, k, v, lse, delta, *, softmax_scale, causal, cu_seqlens_q=None,
+            cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL,
+            k_half=HALF_FULL, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None,
+            acc_init=False, deterministic=False, phases=_C.BWD_ALL):
+        """dQ/dK/dV of one block.  Plain outputs (io dtype) or `+=` into fp32 accumulators.
+        phases=BWD_COMPUTE / BWD_REDUCE splits the call so a ring step can overlap the kernels
+        with the arrival of the dk/dv accumulators it adds into."""
+        self._check_dev(dout, q, k, v, lse, delta, dq, dk, dv, dq_acc, dk_acc, dv_acc)
+        varlen = cu_seqlens_q is not None
+        a = _C.BwdArgs()
+        a.dout, a.q, a.k, a.v = _ptr(dout), _ptr(q), _ptr(k), _ptr(v)
+        a.dout_st, a.q_st = _st3(dout, varlen), _st3(q, varlen)
+        a.k_st, a.v_st = _st3(k, varlen), _st3(v, varlen)
+        a.lse = _ptr(lse)
+        a.lse_batch, a.lse_head = _lse_st(lse, varlen)
+        a.delta = _ptr(delta)
+        a.delta_batch, a.delta_head = _lse_st(delta, varlen)
+        if dq_acc is not None:
+            a.dq_acc, a.dq_acc_st = _ptr(dq_acc), _st3(dq_acc, varlen)
+        else:
+            a.dq, a.dq_st = _ptr(dq), _st3(dq, varlen)
+        if dk_acc is not None:
+            a.dk_acc, a.dv_acc = _ptr(dk_acc), _ptr(dv_acc)
+            a.dk_acc_st, a.dv_acc_st = _st3(dk_acc, varlen), _st3(dv_acc, varlen)
+        else:
+            a.dk, a.dv = _ptr(dk), _ptr(dv)
+            a.dk_st, a.dv_st = _st3(dk, varlen), _st3(dv, varlen)
+        a.acc_init = 1 if acc_init else 0
+        if varlen:
+            a.cu_seqlens_q, a.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+            a.B = cu_seqlens_q.numel() - 1
+            a.H, a.D = q.shape[1], q.shape[2]
+            a.Hk = k.shape[1]
+            a.Sq, a.Sk = int(max_seqlen_q), int(max_seqlen_k)
+            a.total_k = k.shape[0]
+        else:
+            a.B, a.Sq, a.H, a.D = q.shape
+            a.Sk, a.Hk = k.shape[1], k.shape[2]
+            a.total_k = a.B * a.Sk
+        a.q_half, a.k_half = q_half, k_half
+        a.softmax_scale = float(softmax_scale)
+        a.causal = 1 if causal else 0
+        a.deterministic = 1 if deterministic else 0
+        a.dtype = self._dtype(q)
+        a.phases = phases
+        nbytes = self.lib.rfa_bwd_workspace_bytes(C.byref(a))
+        if nbytes:
+            a.workspace = self._workspace(q.device, nbytes).data_ptr()
+        _C.check(self.lib.rfa_bwd(C.byref(a), _stream(q)), "rfa_bwd")
+
+    # ------------------------------------------------------------------ side kernels
+    def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):
+        """Stand-alone (out, lse) merge.  out_acc/block_out: (B,S,H,D) views; lse_acc/block_lse:
+        (B,H,S) views of ANY strides (so the reference's (B,S,H,1) running lse works too)."""
+        self._check_dev(out_acc, lse_acc, block_out, block_lse)
+        if lse_acc.dtype != torch.float32 or block_lse.dtype != torch.float32:
+            raise ValueError("lse tensors must be float32")
+        a = _C.MergeArgs()
+        a.out_acc, a.out_acc_st = _ptr(out_acc), _st3(out_acc, False)
+        a.lse_acc = _ptr(lse_acc)
+        a.lse_acc_batch, a.lse_acc_head, a.lse_acc_row = lse_acc.stride()
+        a.block_out, a.block_out_st = _ptr(block_out), _st3(block_out, False)
+        a.block_lse = _ptr(block_lse)
+        a.block_lse_batch, a.block_lse_head, a.block_lse_row = block_lse.stride()
+        a.B, a.S, a.H, a.D = block_out.shape
+        a.acc_init = 1 if acc_init else 0
+        a.dtype = self._dtype(block_out)
+        _C.check(self.lib.rfa_merge(C.byref(a), _stream(block_out)), "rfa_merge")
+
+    def cast(self, src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """fp32 accumulator -> io dtype (new contiguous tensor)."""
+        self._check_dev(src)
+        if not src.is_contiguous():
+            src = src.contiguous()
+        dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+        _C.check(self.lib.rfa_cast(dst.data_ptr(), src.data_ptr(), src.numel(), _DTYPES[dtype], _stream(src)),
+                 "rfa_cast")
+        return dst
+
+    def lse_flatten(self, lse_padded, cu_seqlens):
+        """(B,H,max_seqlen) -> (H,T)   (triton_utils.flatten_varlen_lse)."""
+        self._check_dev(lse_padded, cu_seqlens)
+        B, H, M = lse_padded.shape
+        T = int(cu_seqlens[-1].item())
+        src = lse_padded.contiguous()
+        dst = torch.empty((H, T), dtype=torch.float32, device=src.device)
+        _C.check(self.lib.rfa_lse_flatten(dst.data_ptr(), src.data_ptr(), cu_seqlens.data_ptr(), B, H, M,
+                                          dst.stride(0), dst.stride(1), _stream(src)), "rfa_lse_flatten")
+        return dst
+
+    def lse_unflatten(self, lse_packed, cu_seqlens, max_seqlen):
+        """(T,H,1)/(T,H) -> (B,H,max_seqlen)   (triton_utils.unflatten_varlen_lse)."""
+        self._check_dev(lse_packed, cu_seqlens)
+        if lse_packed.dim() == 3:
+            lse_packed = lse_packed.squeeze(-1)
+        T, H = lse_packed.shape
+        B = cu_seqlens.numel() - 1
+        dst = torch.empty((B, H, max_seqlen), dtype=torch.float32, device=lse_packed.device)
+        _C.check(self.lib.rfa_lse_unflatten(dst.data_ptr(), lse_packed.data_ptr(), cu_seqlens.data_ptr(), B, H,
+                                            int(max_seqlen), lse_packed.stride(1), lse_packed.stride(0),
+                                            _stream(lse_packed)), "rfa_lse_unflatten")
+        return dst
+
+
+_backend = None
+_injected = None
+
+
+def set_backend(backend):
+    """TEST HOOK ONLY: inject an object with HipBackend's interface (e.g. the CPU oracle from
+    oracle/).  Pass None to restore the HIP backend.  Nothing in the package calls this."""
+    global _injected
+    _injected = backend
+
+
+def get_backend():
+    global _backend
+    if _injected is not None:
+        return _injected
+    if _backend is None:
+        _backend = HipBackend()   # raises RuntimeError if librfa_hip.so is missing
+    return _backend

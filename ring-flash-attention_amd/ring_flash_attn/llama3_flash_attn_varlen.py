@@ -1,0 +1,309 @@
+"""Llama-3 style context parallelism: all-gather K/V per kv-head group, one varlen attention.
+
+Same public surface and semantics as
+/root/reference/ring_flash_attn/llama3_flash_attn_varlen.py (prepare_cu_seqlens :10-60,
+forward :63-158, backward :161-299, autograd :302-387, wrappers :390-504).  The packed token
+stream is cut into W contiguous slices; rank r attends its slice's queries against
+`local_k_slice` of the gathered keys with a bottom-right aligned causal mask.
+
+MI355X-first changes: each head group's attention writes straight into strided views of the
+final `out` / `lse` / `dq` tensors (no `torch.cat`, no per-group temporaries); delta is
+computed once; `prepare_cu_seqlens` does its integer work on one host copy of `cu_seqlens`
+instead of ~10 `.item()` syncs; world_size == 1 collapses to a single kernel for all heads.
+"""
+import torch
+import torch.distributed as dist
+
+from .backend import get_backend
+from .utils import AllGatherComm as Comm, reduce_scatter
+from ._api import _check_unsupported
+from ._common import _as_cu
+
+
+def llama3_flash_attn_prepare_cu_seqlens(cu_seqlens: torch.Tensor, causal: bool, rank: int, world_size: int):
+    """
+    Args:
+        cu_seqlens: torch.Tensor, the cu_seqlens of all the sequences across the ring process group.
+
+    Returns:
+        cu_seqlens_q: torch.Tensor, the cu_seqlens of the q slice for this rank.
+        cu_seqlens_k: torch.Tensor, the cu_seqlens of the k slice that the local q need. Note
+            that this may be longer than `total_seq_len // world_size`.
+        local_k_slice: slice, the slice of the k that the local q need. Note
+            that this may be longer than `total_seq_len // world_size`.
+    """
+    cu = [int(x) for x in cu_seqlens.tolist()]      # one device->host copy
+    total_length = cu[-1]
+    assert total_length % world_size == 0
+    length_per_rank = total_length // world_size
+    lo, hi = rank * length_per_rank, (rank + 1) * length_per_rank
+
+    def searchsorted(val):                           # torch.searchsorted(..., right=False)
+        i = 0
+        while i < len(cu) and cu[i] < val:
+            i += 1
+        return i
+
+    left = searchsorted(lo)
+    right = searchsorted(hi)
+    # after this, cu[left:right + 1] contains all the sequences that touch this rank
+    if cu[left] != lo:
+        left -= 1
+
+    cu_q = [c - lo for c in cu[left:right + 1]]
+    cu_q[0] = 0
+    cu_q[-1] = length_per_rank
+
+    cu_k = list(cu[left:right + 1])
+    if causal:
+        # the last k sequence ends where the last local q sequence ends
+        slice_right = hi
+        cu_k[-1] = slice_right
+    else:
+        # the last k is the full sequence
+        slice_right = cu[right]
+    slice_left = cu[left]
+    cu_k = [c - slice_left for c in cu_k]
+
+    max_seqlen_q = max(b - a for a, b in zip(cu_q[:-1], cu_q[1:]))
+    max_seqlen_k = max(b - a for a, b in zip(cu_k[:-1], cu_k[1:]))
+    local_k_slice = slice(slice_left, slice_right)
+    cu_seqlens_q = torch.tensor(cu_q, dtype=cu_seqlens.dtype, device=cu_seqlens.device)
+    cu_seqlens_k = torch.tensor(cu_k, dtype=cu_seqlens.dtype, device=cu_seqlens.device)
+    return cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, local_k_slice
+
+
+def llama3_flash_attn_varlen_forward(
+    process_group,
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    cu_seqlens_q,
+    cu_seqlens_k,
+    max_seqlen_q,
+    max_seqlen_k,
+    heads_k_stride,
+    local_k_slice,
+    softmax_scale,
+    dropout_p=0,
+    causal=True,
+    window_size=(-1, -1),
+    alibi_slopes=None,
+    deterministic=False,
+):
+    be = get_backend()
+    T, nheads, head_dim = q.shape
+    total_k, nheads_k, _ = k.shape
+    assert nheads_k % heads_k_stride == 0
+    vl = dict(cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, max_seqlen_q=max_seqlen_q,
+              max_seqlen_k=max_seqlen_k)
+
+    out = torch.empty_like(q)
+    lse = torch.empty((nheads, T), dtype=torch.float32, device=q.device)
+    world_size = dist.get_world_size(process_group)
+
+    if world_size == 1:
+        be.fwd(q, k[local_k_slice], v[local_k_slice], softmax_scale=softmax_scale, causal=causal,
+               out=out, lse=lse, **vl)
+        return out, lse
+
+    kv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+    kv_buffer_copy = torch.empty_like(kv_buffer)
+
+    k_0 = k[:, :heads_k_stride].contiguous()
+    v_0 = v[:, :heads_k_stride].contiguous()
+    comm = Comm(process_group)
+    comm.all_gather(kv_buffer_copy[0], k_0)
+    comm.all_gather(kv_buffer_copy[1], v_0)
+
+    for i in range(0, nheads_k, heads_k_stride):
+        comm.wait()
+        kv_buffer, kv_buffer_copy = kv_buffer_copy, kv_buffer
+
+        if i < nheads_k - heads_k_stride:
+            # all_gather the next kv slice while this group's attention runs
+            kv_slice_left = i + heads_k_stride
+            kv_slice_right = kv_slice_left + heads_k_stride
+            send_k = k[:, kv_slice_left:kv_slice_right].contiguous()
+            send_v = v[:, kv_slice_left:kv_slice_right].contiguous()
+            comm.all_gather(kv_buffer_copy[0], send_k)
+            comm.all_gather(kv_buffer_copy[1], send_v)
+
+        q_slice = slice(i * nheads // nheads_k, (i + heads_k_stride) * nheads // nheads_k)
+        be.fwd(q[:, q_slice], kv_buffer[0][local_k_slice], kv_buffer[1][local_k_slice],
+               softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], **vl)
+
+    return out, lse
+
+
+def llama3_flash_attn_varlen_backward(
+    process_group,
+    dout,
+    q,
+    k,
+    v,
+    out,
+    softmax_lse,
+    cu_seqlens_q,
+    cu_seqlens_k,
+    max_seqlen_q,
+    max_seqlen_k,
+    heads_k_stride,
+    local_k_slice,
+    softmax_scale,
+    dropout_p=0,
+    causal=True,
+    window_size=(-1, -1),
+    alibi_slopes=None,
+    deterministic=False,
+):
+    be = get_backend()
+    T, nheads, head_dim = q.shape
+    total_k, nheads_k, _ = k.shape
+    assert nheads_k % heads_k_stride == 0
+    vl = dict(cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k, max_seqlen_q=max_seqlen_q,
+              max_seqlen_k=max_seqlen_k)
+    if not softmax_lse.is_contiguous():
+        softmax_lse = softmax_lse.contiguous()
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
+
+    delta = torch.empty((nheads, T), dtype=torch.float32, device=q.device)
+    be.bwd_preprocess(dout, out, delta, cu_seqlens_q=cu_seqlens_q, max_seqlen_q=max_seqlen_q)
+
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k)
+    dv = torch.empty_like(v)
+    world_size = dist.get_world_size(process_group)
+
+    if world_size == 1:
+        if local_k_slice.start != 0 or local_k_slice.stop != total_k:
+            dk.zero_()
+            dv.zero_()
+        be.bwd(dout, q, k[local_k_slice], v[local_k_slice], softmax_lse, delta, softmax_scale=softmax_scale,
+               causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, **vl)
+        return dq, dk, dv
+
+    kv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+    kv_buffer_copy = torch.empty_like(kv_buffer)
+    dkv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+
+    if heads_k_stride != nheads_k:
+        kv_contiguous_buffer = torch.empty((2, total_k, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+
+    comm = Comm(process_group)
+    k_0 = k[:, :heads_k_stride].contiguous()
+    v_0 = v[:, :heads_k_stride].contiguous()
+    comm.all_gather(kv_buffer_copy[0], k_0)
+    comm.all_gather(kv_buffer_copy[1], v_0)
+
+    for i in range(0, nheads_k, heads_k_stride):
+        dkv_buffer.zero_()
+
+        q_slice = slice(i * nheads // nheads_k, (i + heads_k_stride) * nheads // nheads_k)
+
+        comm.wait()
+        kv_buffer, kv_buffer_copy = kv_buffer_copy, kv_buffer
+
+        if i < nheads_k - heads_k_stride:
+            kv_slice_left = i + heads_k_stride
+            kv_slice_right = kv_slice_left + heads_k_stride
+            send_k = k[:, kv_slice_left:kv_slice_right].contiguous()
+            send_v = v[:, kv_slice_left:kv_slice_right].contiguous()
+            comm.all_gather(kv_buffer_copy[0], send_k)
+            comm.all_gather(kv_buffer_copy[1], send_v)
+
+        be.bwd(dout[:, q_slice], q[:, q_slice], kv_buffer[0][local_k_slice], kv_buffer[1][local_k_slice],
+               softmax_lse[q_slice], delta[q_slice], softmax_scale=softmax_scale, causal=causal,
+               dq=dq[:, q_slice], dk=dkv_buffer[0][local_k_slice], dv=dkv_buffer[1][local_k_slice],
+               deterministic=deterministic, **vl)
+
+        if heads_k_stride != nheads_k:
+            # reduce_scatter needs a contiguous output
+            dk_i = kv_contiguous_buffer[0]
+            dv_i = kv_contiguous_buffer[1]
+        else:
+            dk_i = dk
+            dv_i = dv
+
+        reduce_scatter(dk_i, dkv_buffer[0], group=process_group)
+        reduce_scatter(dv_i, dkv_buffer[1], group=process_group)
+
+        if heads_k_stride != nheads_k:
+            dk[:, i : i + heads_k_stride] = dk_i
+            dv[:, i : i + heads_k_stride] = dv_i
+
+    return dq, dk, dv
+
+
+class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
+    """autograd wrapper; argument order of reference llama3_flash_attn_varlen.py:302-323."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+                local_k_slice, dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic,
+                return_softmax, group):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        if q.stride(-1) != 1:
+            q = q.contiguous()
+        k = k.contiguous()      # all-gather source
+        v = v.contiguous()
+        cu_seqlens_q = _as_cu(cu_seqlens_q, q.device)
+        cu_seqlens_k = _as_cu(cu_seqlens_k, q.device)
+        out, softmax_lse = llama3_flash_attn_varlen_forward(
+            group, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+            local_k_slice, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+            window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+        )
+        ctx.save_for_backward(q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k)
+        ctx.static = (max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice)
+        ctx.softmax_scale = softmax_scale
+        ctx.causal = causal
+        ctx.deterministic = deterministic
+        ctx.group = group
+        return out if not return_softmax else (out, softmax_lse, None)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k = ctx.saved_tensors
+        dq, dk, dv = llama3_flash_attn_varlen_backward(
+            ctx.group, dout, q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, *ctx.static,
+            softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal, window_size=(-1, -1),
+            alibi_slopes=None, deterministic=ctx.deterministic,
+        )
+        return (dq, dk, dv) + (None,) * 15
+
+
+def _make_llama3_api():
+    lead = "cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice"
+
+    def func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+             dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+             deterministic=False, return_attn_probs=False, group=None):
+        return Llama3FlashAttnVarlenFunc.apply(
+            q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+            dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic, return_attn_probs, group)
+
+    def kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+                      local_k_slice, **kw):
+        return func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                    heads_k_stride, local_k_slice, **kw)
+
+    def qkvpacked_func(qkv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+                       local_k_slice, **kw):
+        return func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+                    heads_k_stride, local_k_slice, **kw)
+
+    func.__name__ = func.__qualname__ = "llama3_flash_attn_varlen_func"
+    kvpacked_func.__name__ = kvpacked_func.__qualname__ = "llama3_flash_attn_varlen_kvpacked_func"
+    qkvpacked_func.__name__ = qkvpacked_func.__qualname__ = "llama3_flash_attn_varlen_qkvpacked_func"
+    return func, kvpacked_func, qkvpacked_func
+
+
+(
+    llama3_flash_attn_varlen_func,
+    llama3_flash_attn_varlen_kvpacked_func,
+    llama3_flash_attn_varlen_qkvpacked_func,
+) = _make_llama3_api()

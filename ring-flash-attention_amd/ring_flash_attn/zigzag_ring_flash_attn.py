@@ -1,0 +1,169 @@
+"""Zigzag (causal-balanced) ring attention — the headline path.
+
+Same public surface and step semantics as
+/root/reference/ring_flash_attn/zigzag_ring_flash_attn.py (forward :7-88, backward :91-199,
+autograd Function :202-265, wrappers :268-346): rank r holds sequence chunks r and 2W-1-r;
+at step s it sees the K/V of rank (r-s) mod W and computes
+    s == 0      : local causal block
+    0 < s <= r  : all queries  x first-half keys   (no mask)
+    s > r       : second-half queries x all keys   (no mask)
+MI355X-first differences:
+  * every block result is merged into fp32 (out, lse) accumulators INSIDE the attention
+    kernel's epilogue (rfa_fwd accumulate mode) — no block_out round trip, no merge kernels,
+    and half-slices are plain strided views (pointer offsets), never copies;
+  * lse is kept contiguous (B,H,S) end to end (the reference returns a transposed view);
+  * backward: delta = rowsum(dO*O) once per call; dQ accumulates in fp32 inside the dQ kernel;
+    dK/dV partials are group-summed straight into the travelling fp32 accumulators, split in
+    two phases so the kernels overlap the arrival of those accumulators;
+  * world_size == 1 short-circuits to a single kernel writing q.dtype directly.
+"""
+import torch
+
+from . import _C
+from .backend import get_backend
+from .utils import RingComm
+from ._api import make_autograd_function, make_dense_api
+
+
+def zigzag_ring_flash_attn_forward(
+    process_group,
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    softmax_scale,
+    dropout_p=0,
+    causal=True,
+    window_size=(-1, -1),
+    alibi_slopes=None,
+    deterministic=False,
+):
+    assert causal == True, "zigzag ring is meaningless for causal=False"
+    be = get_backend()
+    comm = RingComm(process_group)
+    B, S, H, D = q.shape
+    half = S // 2
+
+    if comm.world_size == 1:
+        out = torch.empty_like(q)
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse)
+        return out, lse
+
+    out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+    lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    next_k, next_v = None, None
+
+    for step in range(comm.world_size):
+        if step + 1 != comm.world_size:
+            next_k, next_v = comm.send_recv_kv(k, v)
+
+        if step == 0:
+            be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,
+                   out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
+        elif step <= comm.rank:
+            be.fwd(q, k[:, :half], v[:, :half], softmax_scale=softmax_scale, causal=False,
+                   out_acc=out_acc, lse_acc=lse_acc)
+        else:
+            be.fwd(q[:, half:], k, v, softmax_scale=softmax_scale, causal=False,
+                   out_acc=out_acc[:, half:], lse_acc=lse_acc[:, :, half:])
+
+        if step + 1 != comm.world_size:
+            comm.wait()
+            k, v = next_k, next_v
+
+    out = be.cast(out_acc, q.dtype)
+    return out, lse_acc
+
+
+def zigzag_ring_flash_attn_backward(
+    process_group,
+    dout,
+    q,
+    k,
+    v,
+    out,
+    softmax_lse,
+    softmax_scale,
+    dropout_p=0,
+    causal=True,
+    window_size=(-1, -1),
+    alibi_slopes=None,
+    deterministic=False,
+):
+    assert causal == True, "zigzag ring is meaningless for causal=False"
+    be = get_backend()
+    kv_comm = RingComm(process_group)
+    d_kv_comm = RingComm(process_group)
+    B, S, H, D = q.shape
+    half = S // 2
+    if not softmax_lse.is_contiguous():
+        softmax_lse = softmax_lse.contiguous()
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
+
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    be.bwd_preprocess(dout, out, delta)
+
+    if kv_comm.world_size == 1:
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
+               dq=dq, dk=dk, dv=dv, deterministic=deterministic)
+        return dq, dk, dv
+
+    dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+    dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
+    dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
+    next_dk, next_dv = None, None
+    next_k, next_v = None, None
+    dk_comm_buffer, dv_comm_buffer = None, None
+
+    for step in range(kv_comm.world_size):
+        if step + 1 != kv_comm.world_size:
+            next_k, next_v = kv_comm.send_recv_kv(k, v)
+
+        if step == 0:
+            be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
+                   dq_acc=dq, dk_acc=dk, dv_acc=dv, acc_init=True, deterministic=deterministic)
+        else:
+            front = step <= kv_comm.rank
+            if front:
+                args = (dout, q, k[:, :half], v[:, :half], softmax_lse, delta)
+                dq_view = dq
+            else:
+                args = (dout[:, half:], q[:, half:], k, v, softmax_lse[:, :, half:], delta[:, :, half:])
+                dq_view = dq[:, half:]
+            # phase 1: dQ (+= in fp32) and per-head dK/dV partials — overlaps the dk/dv transfer
+            be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
+                   dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_COMPUTE)
+
+            d_kv_comm.wait()
+            dk_comm_buffer, dv_comm_buffer = dk, dv
+            dk, dv = next_dk, next_dv
+
+            # phase 2: add this step's dK/dV into the accumulators that just arrived
+            if front:
+                be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
+                       dk_acc=dk[:, :half], dv_acc=dv[:, :half], deterministic=deterministic,
+                       phases=_C.BWD_REDUCE)
+            else:
+                be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
+                       dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_REDUCE)
+
+        if step + 1 != kv_comm.world_size:
+            kv_comm.wait()
+            k, v = next_k, next_v
+
+        next_dk, next_dv = d_kv_comm.send_recv_kv(dk, dv, dk_comm_buffer, dv_comm_buffer)
+
+    d_kv_comm.wait()
+
+    return be.cast(dq, q.dtype), be.cast(next_dk, q.dtype), be.cast(next_dv, q.dtype)
+
+
+ZigZagRingFlashAttnFunc = make_autograd_function(
+    "ZigZagRingFlashAttnFunc", zigzag_ring_flash_attn_forward, zigzag_ring_flash_attn_backward, 0)
+(
+    zigzag_ring_flash_attn_func,
+    zigzag_ring_flash_attn_kvpacked_func,
+    zigzag_ring_flash_attn_qkvpacked_func,
+) = make_dense_api(ZigZagRingFlashAttnFunc, "zigzag_ring_flash_attn")

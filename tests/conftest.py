@@ -1,0 +1,57 @@
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT, "ring-flash-attention_amd")
+for p in (ROOT, PKG_DIR):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.fixture(scope="session")
+def single_rank_group():
+    """default process group of world size 1 (the public API needs torch.distributed initialised)."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    yield None
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import torch
+
+    return torch.load(os.path.join(ROOT, "tests", "golden", "ring_golden.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
+def built():
+    """make sure the in-tree native artefacts exist (cross-compiles without a GPU)."""
+    sys.path.insert(0, PKG_DIR)
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("rfa_build", os.path.join(PKG_DIR, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.build_lib()
+    mod.build_oracle()
+    return mod

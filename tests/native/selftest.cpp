@@ -118,21 +118,19 @@ __global__ void tr_probe(uint16_t* out /* [16 rb][4 dblk][64 lanes][4] */) {
   const int lane = threadIdx.x;
   for (int idx = lane; idx < 64 * 16; idx += 64) {
     const int row = idx >> 4, chunk = idx & 15;
-    vec8<bf16_t> v;
-    for (int e = 0; e < 8; ++e) {
-      uint16_t val = (uint16_t)(row * 128 + chunk * 8 + e);
-      v[e] = __builtin_bit_cast(bf16_t, val);
-    }
-    lds_write128<bf16_t>(smem + tile_off(row, chunk), v);
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    s16x8 v;
+    for (int e = 0; e < 8; ++e) v[e] = (short)(row * 128 + chunk * 8 + e);
+    *(__attribute__((address_space(3))) s16x8*)(smem + tile_off(row, chunk)) = v;
   }
   __syncthreads();
   for (int rbi = 0; rbi < 16; ++rbi) {
     const int rb = 4 * rbi;
     for (int dblk = 0; dblk < 4; ++dblk) {
       const int off = (rb + ((lane & 15) >> 2)) * kRowBytes + tr_lane_off(lane, dblk, (rb >> 2) & 3);
-      vec4<bf16_t> v = lds_read_tr<bf16_t>(smem + off);
-      for (int j = 0; j < 4; ++j)
-        out[((rbi * 4 + dblk) * 64 + lane) * 4 + j] = __builtin_bit_cast(uint16_t, v[j]);
+      s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+      uint16_t* o = out + ((rbi * 4 + dblk) * 64 + lane) * 4;
+      o[0] = (uint16_t)v[0]; o[1] = (uint16_t)v[1]; o[2] = (uint16_t)v[2]; o[3] = (uint16_t)v[3];
     }
   }
 }

@@ -1,0 +1,141 @@
+"""The C-ABI library loads, exports every symbol include/rfa.h declares, the ctypes mirror has
+the C layout, argument errors are reported without touching a device, and the product path
+fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "rfa.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rfa_[a-z_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(built):
+    from ring_flash_attn import _C
+
+    lib = C.CDLL(built.LIB)
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in rfa.h but not exported"
+        assert name in _C.SYMBOLS, f"{name} not bound in _C.py"
+    assert set(_C.SYMBOLS) == set(declared)
+
+
+def test_ctypes_structs_match_c_layout(built):
+    from ring_flash_attn import _C
+
+    prog = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "rfa.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(rfa_fwd_args), sizeof(rfa_bwd_preprocess_args),
+         sizeof(rfa_bwd_args), sizeof(rfa_merge_args), sizeof(rfa_strides));
+  printf("%zu %zu %zu %zu\n", offsetof(rfa_fwd_args, dtype), offsetof(rfa_bwd_args, phases),
+         offsetof(rfa_bwd_args, total_k), offsetof(rfa_merge_args, block_lse_row));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [int(x) for x in out]
+    assert sizes[:5] == [C.sizeof(_C.FwdArgs), C.sizeof(_C.BwdPreArgs), C.sizeof(_C.BwdArgs),
+                         C.sizeof(_C.MergeArgs), C.sizeof(_C.Strides)]
+    assert sizes[5:] == [_C.FwdArgs.dtype.offset, _C.BwdArgs.phases.offset, _C.BwdArgs.total_k.offset,
+                         _C.MergeArgs.block_lse_row.offset]
+
+
+def test_argument_errors_without_device(built):
+    from ring_flash_attn import _C
+
+    lib = _C.load()
+    assert lib.rfa_abi_version() == _C.RFA_ABI_VERSION
+    assert lib.rfa_fwd(None, None) == -1                      # RFA_ERR_NULL
+    a = _C.FwdArgs()
+    a.B, a.H, a.Hk, a.D, a.Sq, a.Sk, a.dtype = 1, 4, 3, 64, 8, 8, 0
+    assert lib.rfa_fwd(C.byref(a), None) == -4                # H % Hk
+    a.Hk, a.D = 2, 136
+    assert lib.rfa_fwd(C.byref(a), None) == -3                # head dim
+    a.D, a.dtype = 64, 7
+    assert lib.rfa_fwd(C.byref(a), None) == -2                # dtype
+    a.dtype = 0
+    assert lib.rfa_fwd(C.byref(a), None) == -1                # q/k/v NULL
+    a.Sq = 0
+    assert lib.rfa_fwd(C.byref(a), None) == 0                 # empty problem is a no-op
+    assert b"head_dim" in lib.rfa_strerror(-3)
+    b = _C.BwdArgs()
+    b.B, b.H, b.Hk, b.D, b.Sq, b.Sk, b.dtype = 1, 4, 2, 64, 8, 8, 0
+    assert lib.rfa_bwd(C.byref(b), None) == -1
+    b.total_k = 8
+    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 2 * 8 * 4 * 64 * 2
+    b.Hk = 4
+    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 0
+
+
+def test_product_path_has_no_cpu_fallback(built, single_rank_group):
+    """CPU tensors must raise, not silently compute somewhere else."""
+    import ring_flash_attn
+    from ring_flash_attn import backend
+
+    backend.set_backend(None)
+    q = torch.randn(1, 16, 2, 32, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ring_flash_attn.ring_flash_attn_func(q, q, q, causal=True)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ring_flash_attn.zigzag_ring_flash_attn_func(q, q, q, causal=True)
+
+
+def test_missing_extension_fails_loudly(monkeypatch, built):
+    from ring_flash_attn import _C
+
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", "/nonexistent/librfa_hip.so")
+    with pytest.raises(RuntimeError, match="not built"):
+        _C.load()
+
+
+def test_public_api_surface():
+    """the 21 public names of reference ring_flash_attn/__init__.py:1-35 minus stripe_* (out of scope)."""
+    import inspect
+    import ring_flash_attn as r
+
+    tail = ["dropout_p", "softmax_scale", "causal", "window_size", "alibi_slopes", "deterministic",
+            "return_attn_probs", "group"]
+    for prefix, lead in (("ring_flash_attn", []), ("zigzag_ring_flash_attn", []),
+                         ("ring_flash_attn_varlen", ["cu_seqlens", "max_seqlen"]),
+                         ("zigzag_ring_flash_attn_varlen", ["cu_seqlens", "max_seqlen"])):
+        for suffix, first in (("func", ["q", "k", "v"]), ("kvpacked_func", ["q", "kv"]), ("qkvpacked_func", ["qkv"])):
+            fn = getattr(r, f"{prefix}_{suffix}")
+            assert list(inspect.signature(fn).parameters) == first + lead + tail
+    sig = list(inspect.signature(r.llama3_flash_attn_varlen_func).parameters)
+    assert sig == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "heads_k_stride",
+                   "local_k_slice"] + tail
+    assert list(inspect.signature(r.llama3_flash_attn_prepare_cu_seqlens).parameters) == ["cu_seqlens", "causal", "rank", "world_size"]
+    assert callable(r.substitute_hf_flash_attn) and callable(r.update_ring_flash_attn_params)
+
+
+def test_prepare_cu_seqlens_golden(golden):
+    """bit-exact integer parity with the reference's llama3_flash_attn_prepare_cu_seqlens
+    (llama3_flash_attn_varlen.py:10-60) on its own test fixture [0,7,14,16] x 8 ranks and more."""
+    from ring_flash_attn import llama3_flash_attn_prepare_cu_seqlens
+
+    assert len(golden["prepare_cu_seqlens"]) > 50
+    for g in golden["prepare_cu_seqlens"]:
+        cu = torch.tensor(g["cu"], dtype=torch.int32)
+        cq, ck, mq, mk, sl = llama3_flash_attn_prepare_cu_seqlens(cu, g["causal"], g["rank"], g["W"])
+        assert cq.dtype == torch.int32 and cq.tolist() == g["cu_q"] and ck.tolist() == g["cu_k"]
+        assert (mq, mk) == (g["max_q"], g["max_k"]) and (sl.start, sl.stop) == tuple(g["k_slice"])

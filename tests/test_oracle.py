@@ -1,0 +1,132 @@
+"""Pins the oracle (oracle/flash_attn_ref.py, oracle/attn_ref.c).
+
+The reference's tests contain no numeric golden vectors for the flash_attn boundary
+(SURVEY.md §8c), so the oracle is pinned against an INDEPENDENT formulation: plain softmax
+attention in fp64 with torch autograd — the same role `flash_attn_*_func` on the full sequence
+plays in the reference tests (test/test_zigzag_ring_flash_attn_func.py:55-63).
+Tolerances: the oracle computes in fp32 from bf16 inputs -> 2e-5 abs vs fp64 on fp32 outputs;
+outputs rounded to bf16 -> half a bf16 ulp (2^-9 relative).
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from oracle import flash_attn_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SHAPES = [
+    # B, Sq, Sk, H, Hk, D, causal
+    (1, 64, 64, 2, 2, 32, True),
+    (2, 100, 100, 4, 2, 64, True),
+    (1, 48, 130, 4, 1, 32, True),     # bottom-right aligned
+    (1, 130, 48, 2, 2, 32, True),     # rows without keys
+    (1, 77, 93, 3, 3, 16, False),
+]
+
+
+def _rand(shape, seed, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal", SHAPES)
+def test_oracle_vs_fp64_autograd(B, Sq, Sk, H, Hk, D, causal):
+    q, k, v = _rand((B, Sq, H, D), 1), _rand((B, Sk, Hk, D), 2), _rand((B, Sk, Hk, D), 3)
+    do = _rand((B, Sq, H, D), 4)
+    scale = D ** -0.5
+    out, lse, _, _ = R._flash_attn_forward(q.float(), k.float(), v.float(), 0.0, scale, causal)
+    qd, kd, vd = [t.double().requires_grad_(True) for t in (q, k, v)]
+    ro, rl = R.full_attention_fp64(qd, kd, vd, causal, scale)
+    empty = torch.isinf(rl) & (rl < 0)
+    assert torch.equal(torch.isinf(lse) & (lse > 0), empty)       # flash_attn: +inf for empty rows
+    assert (out.double() - ro).abs().max() < 2e-5
+    assert (lse.double() - rl)[~empty].abs().max() < 2e-5
+    ro.backward(do.double())
+    dq, dk, dv = torch.empty_like(q, dtype=torch.float32), torch.empty_like(k, dtype=torch.float32), torch.empty_like(v, dtype=torch.float32)
+    R._flash_attn_backward(do.float(), q.float(), k.float(), v.float(), out, lse, dq, dk, dv, 0.0, scale, causal)
+    for got, ref in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_oracle_rounds_like_flash_attn():
+    q, k, v = _rand((1, 40, 2, 32), 1), _rand((1, 40, 2, 32), 2), _rand((1, 40, 2, 32), 3)
+    out, lse, _, _ = R._flash_attn_forward(q, k, v, 0.0, 32 ** -0.5, True)
+    assert out.dtype == torch.bfloat16 and lse.dtype == torch.float32 and lse.shape == (1, 2, 40)
+    ro, _ = R.full_attention_fp64(q, k, v, True)
+    assert (out.double() - ro).abs().max() <= 2 ** -8 * ro.abs().max()
+
+
+def test_oracle_varlen_equals_per_sequence_dense():
+    cu = torch.tensor([0, 15, 156, 200], dtype=torch.int32)
+    cuk = torch.tensor([0, 40, 190, 300], dtype=torch.int32)
+    H, Hk, D = 4, 2, 32
+    q, k, v = _rand((200, H, D), 1), _rand((300, Hk, D), 2), _rand((300, Hk, D), 3)
+    do = _rand((200, H, D), 4)
+    out, lse, _, _ = R._flash_attn_varlen_forward(q, k, v, cu, cuk, 141, 150, 0.0, D ** -0.5, True)
+    assert lse.shape == (H, 200)                                   # packed (nheads, total) layout
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    R._flash_attn_varlen_backward(do, q, k, v, out, lse, dq, dk, dv, cu, cuk, 141, 150, 0.0, D ** -0.5, True)
+    for i in range(3):
+        a, b, c, d = cu[i], cu[i + 1], cuk[i], cuk[i + 1]
+        o1, l1, _, _ = R._flash_attn_forward(q[None, a:b], k[None, c:d], v[None, c:d], 0.0, D ** -0.5, True)
+        assert torch.equal(o1[0], out[a:b]) and torch.equal(l1[0], lse[:, a:b])
+        g = [torch.zeros_like(t) for t in (q[None, a:b], k[None, c:d], v[None, c:d])]
+        R._flash_attn_backward(do[None, a:b], q[None, a:b], k[None, c:d], v[None, c:d], o1, l1, *g, 0.0, D ** -0.5, True)
+        assert torch.equal(g[0][0], dq[a:b]) and torch.equal(g[1][0], dk[c:d]) and torch.equal(g[2][0], dv[c:d])
+
+
+def _load_c_oracle(built):
+    lib = C.CDLL(built.ORACLE_LIB)
+    f = C.POINTER(C.c_float)
+    i32 = C.POINTER(C.c_int32)
+    lib.rfa_ref_fwd.argtypes = [f, f, f, f, f] + [C.c_int] * 6 + [i32, i32, C.c_int64, C.c_float, C.c_int]
+    lib.rfa_ref_bwd.argtypes = [f] * 9 + [C.c_int] * 6 + [i32, i32, C.c_int64, C.c_int64, C.c_float, C.c_int]
+    lib.rfa_ref_merge.argtypes = [f, f, f, f] + [C.c_int] * 4
+    return lib
+
+
+def _fp(t):
+    return t.contiguous().data_ptr()
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal", SHAPES[:4])
+def test_c_oracle_matches_python_oracle(built, B, Sq, Sk, H, Hk, D, causal):
+    lib = _load_c_oracle(built)
+    q, k, v, do = [_rand(s, i).float() for i, s in enumerate([(B, Sq, H, D), (B, Sk, Hk, D), (B, Sk, Hk, D), (B, Sq, H, D)])]
+    scale = D ** -0.5
+    out, lse = torch.empty_like(q), torch.empty(B, H, Sq)
+    P = lambda t: C.cast(_fp(t), C.POINTER(C.c_float))
+    assert lib.rfa_ref_fwd(P(q), P(k), P(v), P(out), P(lse), B, H, Hk, D, Sq, Sk, None, None, 0, scale, int(causal)) == 0
+    po, pl, _, _ = R._flash_attn_forward(q, k, v, 0.0, scale, causal)
+    assert (out - po).abs().max() < 1e-5
+    fin = ~torch.isinf(pl)
+    assert torch.equal(torch.isinf(lse), torch.isinf(pl)) and (lse - pl)[fin].abs().max() < 1e-5
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    assert lib.rfa_ref_bwd(P(do), P(q), P(k), P(v), P(out), P(lse), P(dq), P(dk), P(dv), B, H, Hk, D, Sq, Sk,
+                           None, None, 0, 0, scale, int(causal)) == 0
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    R._flash_attn_backward(do, q, k, v, po, pl, gq, gk, gv, 0.0, scale, causal)
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        assert (a - b).abs().max() < 5e-5 * max(1.0, b.abs().max().item())
+
+
+def test_c_oracle_merge_is_reference_formula(built):
+    """rfa_ref_merge restates _update_out_and_lse (reference utils.py:40-48)."""
+    import torch.nn.functional as F
+
+    lib = _load_c_oracle(built)
+    B, S, H, D = 2, 17, 3, 8
+    g = torch.Generator().manual_seed(0)
+    out, bo = torch.randn(B, S, H, D, generator=g), torch.randn(B, S, H, D, generator=g)
+    lse, bl = torch.randn(B, H, S, generator=g) * 3, torch.randn(B, H, S, generator=g) * 3
+    l4, b4 = lse.transpose(1, 2).unsqueeze(-1), bl.transpose(1, 2).unsqueeze(-1)
+    ref_o = out - torch.sigmoid(b4 - l4) * (out - bo)
+    ref_l = (l4 - F.logsigmoid(l4 - b4)).squeeze(-1).transpose(1, 2)
+    o2, l2 = out.clone(), lse.clone()
+    P = lambda t: C.cast(_fp(t), C.POINTER(C.c_float))
+    lib.rfa_ref_merge(P(o2), P(l2), P(bo), P(bl.contiguous()), B, S, H, D)
+    assert (o2 - ref_o).abs().max() < 1e-6 and (l2 - ref_l).abs().max() < 1e-6
+    assert (l2 - torch.logaddexp(lse, bl)).abs().max() < 1e-6      # == logaddexp
