@@ -150,7 +150,14 @@ typedef struct {
   int32_t phases;
 } rfa_bwd_args;
 
-enum { RFA_BWD_ALL = 0, RFA_BWD_COMPUTE = 1, RFA_BWD_REDUCE = 2 };
+enum {
+  RFA_BWD_ALL = 0,
+  RFA_BWD_COMPUTE = 1,
+  RFA_BWD_REDUCE = 2,
+  /* measurement aids, valid together with RFA_BWD_COMPUTE: launch only one of the two kernels */
+  RFA_BWD_SKIP_DKDV = 4,
+  RFA_BWD_SKIP_DQ = 8
+};
 
 typedef struct {
   float *out_acc;          /* (B,S,H,D) fp32, updated in place */

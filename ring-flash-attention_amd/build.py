@@ -75,7 +75,8 @@ def build_selftest(force=False):
     deps = [SELFTEST_SRC, LIB, ORACLE_LIB, os.path.join(CSRC, "rfa_common.hpp")]
     if not force and not _stale(SELFTEST_BIN, deps):
         return SELFTEST_BIN
-    _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", SELFTEST_SRC, "-o", SELFTEST_BIN,
+    _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value",
+          SELFTEST_SRC, "-o", SELFTEST_BIN,
           "-L" + os.path.dirname(LIB), "-lrfa_hip", "-L" + os.path.dirname(ORACLE_LIB), "-lattn_ref",
           "-Wl,-rpath,$ORIGIN/../../ring-flash-attention_amd/ring_flash_attn",
           "-Wl,-rpath,$ORIGIN/../../oracle"])

@@ -171,8 +171,8 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   const bool do_compute = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_COMPUTE);
   const bool do_reduce = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_REDUCE);
   if (do_compute) {
-    if (launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
-    if (launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+    if (!(a->phases & RFA_BWD_SKIP_DQ) && launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+    if (!(a->phases & RFA_BWD_SKIP_DKDV) && launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
   }
   if (ws && do_reduce) {
     for (int which = 0; which < 2; ++which) {

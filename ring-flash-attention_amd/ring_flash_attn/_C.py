@@ -13,6 +13,7 @@ RFA_ABI_VERSION = 1
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
+BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
 
 
 class Strides(C.Structure):

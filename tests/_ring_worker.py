@@ -1,0 +1,105 @@
+"""Multi-process worker shared by the schedule tests: runs the package's public functions on one
+rank of a gloo ring and compares against the golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py).  Backend: the CPU oracle (not-gpu tests, schedules only) or the
+real HIP kernels with every rank sharing cuda:0 (gpu tests; gloo stages through host memory)."""
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ring-flash-attention_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# tolerance of one comparison: |got - ref| <= atol + rtol * max|ref|
+TOL_ORACLE = dict(out=(2e-2, 0.0), lse=(1e-5, 1e-5), grad=(3e-2, 1e-2))
+# HIP kernels vs reference-with-oracle: both round block results to bf16 at different points
+TOL_HIP = dict(out=(2e-2, 1e-2), lse=(2e-4, 1e-4), grad=(3e-2, 2e-2))
+
+
+def _cmp(name, got, ref, tol, errs):
+    got, ref = got.float(), ref.float()
+    if got.shape != ref.shape:
+        errs.append(f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}")
+        return
+    atol, rtol = tol
+    diff = (got - ref).abs().max().item()
+    lim = atol + rtol * ref.abs().max().item()
+    if not (diff <= lim):
+        errs.append(f"{name}: max|diff| {diff:.3e} > {lim:.3e}")
+
+
+def run_rank(rank, W, port, names, use_hip, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=W)
+        import make_golden as MG
+        import ring_flash_attn as R
+        from ring_flash_attn import backend
+
+        golden = torch.load(os.path.join(ROOT, "tests", "golden", "ring_golden.pt"), weights_only=False)
+        if use_hip:
+            dev = torch.device("cuda:0")
+            torch.cuda.set_device(dev)
+            backend.set_backend(None)
+            tol = TOL_HIP
+        else:
+            from oracle.oracle_backend import OracleBackend
+
+            dev = torch.device("cpu")
+            backend.set_backend(OracleBackend())
+            tol = TOL_ORACLE
+        errs = []
+        for n in names:
+            c = MG.CASES[n]
+            (q, k, v, do), extra = MG.shard(c, rank)
+            assert torch.equal(MG.make_inputs(c)[0], golden["cases"][n]["inputs"]["q"]), "seeded inputs drifted"
+            ref = golden["cases"][n]["ranks"][rank]
+            q, k, v, do = [t.to(dev) for t in (q, k, v, do)]
+            q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
+            kw = dict(dropout_p=0.0, window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=True)
+            kind = c["kind"]
+            if kind == "zigzag":
+                out, lse, _ = R.zigzag_ring_flash_attn_func(q, k, v, causal=True, **kw)
+            elif kind == "ring":
+                out, lse, _ = R.ring_flash_attn_func(q, k, v, causal=c["causal"], **kw)
+            elif kind == "zigzag_varlen":
+                out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(q, k, v, extra["cu_local"].to(dev), extra["max_local"], causal=True, **kw)
+            elif kind == "ring_varlen":
+                out, lse, _ = R.ring_flash_attn_varlen_func(q, k, v, extra["cu_local"].to(dev), extra["max_local"], causal=c["causal"], **kw)
+            elif kind == "llama3":
+                cu = torch.tensor(c["cu"], dtype=torch.int32)
+                cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, rank, W)
+                if cq.tolist() != ref["cu_q"].tolist() or ck.tolist() != ref["cu_k"].tolist() or (sl.start, sl.stop) != tuple(ref["k_slice"]):
+                    errs.append(f"{n}: prepare_cu_seqlens mismatch")
+                out, lse, _ = R.llama3_flash_attn_varlen_func(q, k, v, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=c["stride"],
+                                                              local_k_slice=sl, causal=True, **kw)
+            out.backward(do)
+            _cmp(f"{n}[r{rank}].out", out.detach().cpu(), ref["out"], tol["out"], errs)
+            _cmp(f"{n}[r{rank}].lse", lse.detach().cpu(), ref["lse"], tol["lse"], errs)
+            _cmp(f"{n}[r{rank}].dq", q.grad.cpu(), ref["dq"], tol["grad"], errs)
+            _cmp(f"{n}[r{rank}].dk", k.grad.cpu(), ref["dk"], tol["grad"], errs)
+            _cmp(f"{n}[r{rank}].dv", v.grad.cpu(), ref["dv"], tol["grad"], errs)
+            if out.dtype != torch.bfloat16 or q.grad.dtype != torch.bfloat16 or lse.dtype != torch.float32:
+                errs.append(f"{n}: output dtypes {out.dtype} {q.grad.dtype} {lse.dtype}")
+        ret[rank] = errs
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = ["EXC: " + traceback.format_exc()]
+
+
+def run_world(W, names, use_hip, port):
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(run_rank, args=(W, port, names, use_hip, ret), nprocs=W, join=True)
+    errs = []
+    for r in range(W):
+        errs += list(ret.get(r, [f"rank {r} produced no result"]))
+    return errs

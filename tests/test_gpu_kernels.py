@@ -1,0 +1,211 @@
+"""GPU parity tests proper (`-m gpu`): the HIP path, called through the C ABI (ctypes ->
+librfa_hip.so), against the CPU oracle on the same seeded inputs — on the reference's own fixture
+shapes (3824/5/128 zigzag, 3816/5/128 ring, cu_seqlens [0,128,1248,4240] /
+[0,120,1248,4232], llama3 D=8) — plus the side kernels.
+
+Stated tolerances (bf16 inputs N(0,1), fp32 accumulation; the oracle computes in fp32 and rounds
+out/dq/dk/dv to bf16 like flash_attn):
+    out  : |err| <= 2e-2 abs           lse : |err| <= 1e-3 abs
+    grads: |err| <= 2e-2 * max|ref| + 1e-2
+"""
+import os
+import subprocess
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BF = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _check(name, got, ref, atol, rtol=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: {got.shape} vs {ref.shape}"
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(got), fin), f"{name}: non-finite pattern differs"
+    diff = (got - ref)[fin].abs().max().item() if fin.any() else 0.0
+    lim = atol + rtol * ref[fin].abs().max().item()
+    assert diff <= lim, f"{name}: max|err| {diff:.3e} > {lim:.3e}"
+
+
+def _oracle_dense(q, k, v, do, causal):
+    from oracle import flash_attn_ref as O
+
+    scale = q.shape[-1] ** -0.5
+    out, lse, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, causal)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, out, lse, dq, dk, dv, 0.0, scale, causal)
+    return out, lse, dq, dk, dv
+
+
+def _oracle_varlen(q, k, v, do, cu_q, cu_k, causal):
+    from oracle import flash_attn_ref as O
+
+    scale = q.shape[-1] ** -0.5
+    out, lse, _, _ = O._flash_attn_varlen_forward(q, k, v, cu_q, cu_k, 0, 0, 0.0, scale, causal)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, 0, 0, 0.0, scale, causal)
+    return out, lse, dq, dk, dv
+
+
+def _grads_ok(prefix, got, ref):
+    for n, g, r in zip(("dq", "dk", "dv"), got, ref):
+        _check(f"{prefix}.{n}", g, r, 1e-2, 2e-2)
+
+
+def test_native_selftest_binary(built):
+    """torch-free C-ABI self test: layout probes + 20 parity groups against oracle/attn_ref.c"""
+    exe = built.build_selftest()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "SELFTEST PASSED" in r.stdout
+
+
+@pytest.mark.parametrize("api,seqlen,causal", [("zigzag", 3824, True), ("ring", 3816, True), ("ring", 1000, False)])
+def test_dense_qkvpacked_reference_fixture(single_rank_group, api, seqlen, causal):
+    """reference test/test_{zigzag_,}ring_flash_attn_func.py at world_size 1: B=1, H=5, D=128 bf16."""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(42)
+    qkv = torch.randn(1, seqlen, 3, 5, 128, generator=g).to(BF)
+    do = torch.randn(1, seqlen, 5, 128, generator=g).to(BF)
+    fn = R.zigzag_ring_flash_attn_qkvpacked_func if api == "zigzag" else R.ring_flash_attn_qkvpacked_func
+    x = qkv.to(dev).requires_grad_(True)
+    out, lse, _ = fn(x, dropout_p=0, causal=causal, window_size=(-1, -1), alibi_slopes=None, deterministic=False,
+                     return_attn_probs=True)
+    out.backward(do.to(dev))
+    ro, rl, dq, dk, dv = _oracle_dense(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], do, causal)
+    assert out.dtype == BF and lse.dtype == torch.float32 and lse.shape == (1, 5, seqlen) and lse.is_contiguous()
+    _check("out", out, ro, 2e-2)
+    _check("lse", lse, rl, 1e-3)
+    _grads_ok(api, (x.grad[:, :, 0], x.grad[:, :, 1], x.grad[:, :, 2]), (dq, dk, dv))
+
+
+@pytest.mark.parametrize("api,cu", [("zigzag", [0, 128, 1248, 4240]), ("ring", [0, 120, 1248, 4232])])
+def test_varlen_reference_fixture(single_rank_group, api, cu):
+    """reference test/test_{zigzag_,}ring_flash_attn_varlen_func.py at world_size 1 (H=5, D=128)."""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(43)
+    T = cu[-1]
+    qkv = torch.randn(T, 3, 5, 128, generator=g).to(BF)
+    do = torch.randn(T, 5, 128, generator=g).to(BF)
+    cut = torch.tensor(cu, dtype=torch.int32)
+    maxlen = int((cut[1:] - cut[:-1]).max())
+    fn = R.zigzag_ring_flash_attn_varlen_qkvpacked_func if api == "zigzag" else R.ring_flash_attn_varlen_qkvpacked_func
+    x = qkv.to(dev).requires_grad_(True)
+    out, lse, _ = fn(x, cut.to(dev), maxlen, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    ro, rl, dq, dk, dv = _oracle_varlen(qkv[:, 0], qkv[:, 1], qkv[:, 2], do, cut, cut, True)
+    assert lse.shape == (5, T)
+    _check("out", out, ro, 2e-2)
+    _check("lse", lse, rl, 1e-3)
+    _grads_ok(api + "_varlen", (x.grad[:, 0], x.grad[:, 1], x.grad[:, 2]), (dq, dk, dv))
+
+
+def test_llama3_reference_fixture(single_rank_group):
+    """reference test/test_llama3_flash_attn_varlen_func.py at world_size 1: H=5, D=8, stride 1."""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    cu = torch.tensor([0, 120, 1248, 4232], dtype=torch.int32)
+    g = torch.Generator().manual_seed(44)
+    qkv = torch.randn(4232, 3, 5, 8, generator=g).to(BF)
+    do = torch.randn(4232, 5, 8, generator=g).to(BF)
+    cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, causal=True, rank=0, world_size=1)
+    x = qkv.to(dev).requires_grad_(True)
+    out, lse, _ = R.llama3_flash_attn_varlen_qkvpacked_func(x, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=1,
+                                                            local_k_slice=sl, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    ro, rl, dq, dk, dv = _oracle_varlen(qkv[:, 0], qkv[:, 1], qkv[:, 2], do, cu, cu, True)
+    _check("out", out, ro, 2e-2)
+    _check("lse", lse, rl, 1e-3)
+    _grads_ok("llama3", (x.grad[:, 0], x.grad[:, 1], x.grad[:, 2]), (dq, dk, dv))
+
+
+def test_gqa_kvpacked_strided_views_and_fp16(single_rank_group):
+    """benchmark layout (kv packed, GQA 8:2) — K/V are strided views, not copied — and fp16."""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    for dtype in (BF, torch.float16):
+        g = torch.Generator().manual_seed(45)
+        q = torch.randn(2, 777, 8, 128, generator=g).to(dtype)
+        kv = torch.randn(2, 777, 2, 2, 128, generator=g).to(dtype)
+        do = torch.randn(2, 777, 8, 128, generator=g).to(dtype)
+        qd, kvd = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+        out, lse, _ = R.zigzag_ring_flash_attn_kvpacked_func(qd, kvd, causal=True, return_attn_probs=True)
+        out.backward(do.to(dev))
+        ro, rl, dq, dk, dv = _oracle_dense(q, kv[:, :, 0], kv[:, :, 1], do, True)
+        assert out.dtype == dtype
+        _check("out", out, ro, 2e-2)
+        _check("lse", lse, rl, 1e-3)
+        _grads_ok(str(dtype), (qd.grad, kvd.grad[:, :, 0], kvd.grad[:, :, 1]), (dq, dk, dv))
+
+
+def test_merge_kernel_is_reference_update_out_and_lse():
+    """update_out_and_lse (HIP merge kernel) == reference utils.py:40-48 formula, incl. slice_."""
+    import torch.nn.functional as F
+    from ring_flash_attn.utils import update_out_and_lse
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, S, H, D = 2, 333, 5, 128
+    b0, b1 = torch.randn(B, S, H, D, generator=g).to(BF), torch.randn(B, S, H, D, generator=g).to(BF)
+    b2 = torch.randn(B, S - 100, H, D, generator=g).to(BF)
+    l0, l1 = torch.randn(B, H, S, generator=g) * 4, torch.randn(B, H, S, generator=g) * 4
+    l2 = torch.randn(B, H, S - 100, generator=g) * 4
+
+    def ref_update(out, lse, bo, bl):
+        bo = bo.float()
+        bl = bl.transpose(-2, -1).unsqueeze(-1)
+        return out - torch.sigmoid(bl - lse) * (out - bo), lse - F.logsigmoid(lse - bl)
+
+    ro, rl = b0.float(), l0.transpose(-2, -1).unsqueeze(-1)
+    ro, rl = ref_update(ro, rl, b1, l1)
+    so, sl_ = ref_update(ro[:, 100:], rl[:, 100:], b2, l2)
+    ro = ro.clone(); rl = rl.clone()
+    ro[:, 100:], rl[:, 100:] = so, sl_
+
+    out, lse = update_out_and_lse(None, None, b0.to(dev), l0.to(dev))
+    assert out.dtype == torch.float32 and lse.shape == (B, S, H, 1)
+    out, lse = update_out_and_lse(out, lse, b1.to(dev), l1.to(dev))
+    out, lse = update_out_and_lse(out, lse, b2.to(dev), l2.to(dev), slice_=(slice(None), slice(100, None)))
+    _check("merge.out", out, ro, 1e-5, 1e-5)
+    _check("merge.lse", lse, rl, 1e-5, 1e-5)
+    with pytest.raises(RuntimeError, match="first update_out_and_lse"):
+        update_out_and_lse(None, None, b0.to(dev), l0.to(dev), slice_=(slice(None),))
+
+
+def test_lse_flatten_unflatten_bit_exact():
+    """reference test/test_triton_kernels.py: re-layout must be bit-identical (cu [0,15,156,529])."""
+    from ring_flash_attn.utils import flatten_varlen_lse, unflatten_varlen_lse
+
+    dev = _dev()
+    cu = [0, 15, 156, 529]
+    cut = torch.tensor(cu, dtype=torch.int32, device=dev)
+    maxlen = max(b - a for a, b in zip(cu[:-1], cu[1:]))
+    lse = torch.randn(3, 5, maxlen, device=dev)
+    flat = flatten_varlen_lse(lse, cut)
+    ref = torch.cat([lse[i, :, : cu[i + 1] - cu[i]] for i in range(3)], dim=1)
+    assert flat.shape == (5, 529) and torch.equal(flat, ref)
+    un = unflatten_varlen_lse(flat.transpose(-2, -1).unsqueeze(-1), cut, maxlen)
+    for i in range(3):
+        n = cu[i + 1] - cu[i]
+        assert torch.equal(un[i, :, :n], lse[i, :, :n])
+
+
+def test_smoke_entry(single_rank_group):
+    import __graft_entry__ as ge
+
+    ge.smoke()
