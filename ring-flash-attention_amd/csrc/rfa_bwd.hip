@@ -32,7 +32,7 @@ constexpr int kDqKV = 64;
 constexpr int kDqTileBytes = kDqKV * kRowBytes; // 16 KiB
 constexpr int kDqSmem = 4 * kDqTileBytes;       // K[2] V[2]
 
-template <typename T>
+template <typename T, bool kFullD>
 __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     const int d0 = 16 * kk + 8 * g;
-    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
-    dof[kk] = d0 < p.D ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
+    qf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+    dof[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
   }
   const float L2 = p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + arow] * kLog2e;
   const float dlt = p.delta[qbatch * p.delta_batch + (int64_t)h * p.delta_head + arow];
@@ -89,13 +89,14 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 
   const int sc = tid & 15;
   const int sr = tid >> 4;
-  const bool sd_ok = sc * 8 < p.D;
+  const bool sd_ok = kFullD || sc * 8 < p.D;
   vec8<T> kreg[2], vreg[2];
   auto load_tile = [&](int j) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int kr = j * kDqKV + sr + 32 * i;
       kr = kr < lk ? kr : lk - 1;
+      kr = kr < 0 ? 0 : kr;
       if (sd_ok) {
         kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
         vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
@@ -132,10 +133,9 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-  if (ntiles > 0) {
-    load_tile(0);
-    write_tile(0);
-  }
+  load_tile(0);            // unconditional (rows clamped): one path into the loop, see rfa_fwd.hip
+  write_tile(0);
+  wait_all_vmem();
   __syncthreads();
 
   for (int j = 0; j < ntiles; ++j) {
@@ -153,25 +153,39 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        {
+          // S^T = K Q^T and dP^T = V dO^T as one 16-step pipeline, A fragments read kAhead ahead
+          constexpr int kAhead = 3;
+          vec8<T> a[16];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          vec8<T> a = lds_read128<T>(kb + t * 32 * kRowBytes + koff[kk]);
-          s = mfma(a, qf[kk], s);
-        }
+          for (int i = 0; i < kAhead; ++i)
+            a[i] = lds_read128<T>((i < 8 ? kb : vb) + t * 32 * kRowBytes + koff[i & 7]);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          vec8<T> a = lds_read128<T>(vb + t * 32 * kRowBytes + koff[kk]);
-          dp = mfma(a, dof[kk], dp);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pv = fast_exp2(__builtin_fmaf(s[r], c, -L2));
-          if (need_mask) {
-            const int key = kt0 + 32 * t + crow(r, g);
-            pv = key > lim ? 0.f : pv;
+          for (int i = 0; i < 16; ++i) {
+            if (i + kAhead < 16)
+              a[i + kAhead] = lds_read128<T>(((i + kAhead) < 8 ? kb : vb) + t * 32 * kRowBytes + koff[(i + kAhead) & 7]);
+            if (i < 8) s = mfma(a[i], qf[i], s);
+            else dp = mfma(a[i], dof[i - 8], dp);
           }
-          s[r] = pv * (dp[r] - dlt);
+          __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+          for (int i = 0; i < 16 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(__builtin_fmaf(s[r], c, -L2));
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt0 + 32 * t + crow(r, g);
+            s[r] = key > lim ? 0.f : s[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> dsb = pack8<T>(s, 8 * ks2);
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (d0 < p.D) {
+        if (kFullD || d0 < p.D) {
           f32x4 x;
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = dq[dblk][4 * jj + e] * p.scale;
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (d0 < p.D) {
+        if (kFullD || d0 < p.D) {
           f32x4 x;
           if (p.acc_init) {
 #pragma unroll
@@ -240,7 +254,7 @@ constexpr int kKvTileBytes = kKvQ * kRowBytes;    // 16 KiB
 constexpr int kKvStatBytes = 2 * kKvQ * 4;        // lse2[64] + delta[64] per stage
 constexpr int kKvSmem = 4 * kKvTileBytes + 2 * kKvStatBytes;   // Q[2] dO[2] stats[2]
 
-template <typename T>
+template <typename T, bool kFullD>
 __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -289,8 +303,8 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     const int d0 = 16 * kk + 8 * g;
-    kf[kk] = d0 < p.D ? *(const vec8<T>*)(kbase + d0) : zero8<T>();
-    vf[kk] = d0 < p.D ? *(const vec8<T>*)(vbase + d0) : zero8<T>();
+    kf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(kbase + d0) : zero8<T>();
+    vf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(vbase + d0) : zero8<T>();
   }
 
   // query tile range: causal => only rows q with q + off >= first key of the block
@@ -305,7 +319,7 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
   // staging: thread -> chunk sc of rows sr + 16 i (i = 0..3), for Q and dO
   const int sc = tid & 15;
   const int sr = tid >> 4;                    // 0..15
-  const bool sd_ok = sc * 8 < p.D;
+  const bool sd_ok = kFullD || sc * 8 < p.D;
   vec8<T> qreg[4], doreg[4];
   float statreg = 0.f;
   auto load_tile = [&](int j) {
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
     for (int i = 0; i < 4; ++i) {
       int qr = j * kKvQ + sr + 16 * i;
       qr = qr < lq ? qr : lq - 1;
+      qr = qr < 0 ? 0 : qr;
       if (sd_ok) {
         qreg[i] = *(const vec8<T>*)(qbase + (int64_t)qr * p.q_st.row + sc * 8);
         doreg[i] = *(const vec8<T>*)(dobase + (int64_t)qr * p.dout_st.row + sc * 8);
@@ -321,10 +336,14 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
         doreg[i] = zero8<T>();
       }
     }
-    if (tid < 2 * kKvQ) {
+    {
+      // every thread issues this 4-byte load (no branch, no use of the value here: a use would
+      // make hipcc wait vmcnt(0) right behind the tile prefetch); threads >= 128 just discard it
       int qr = j * kKvQ + (tid & (kKvQ - 1));
       qr = qr < lq ? qr : lq - 1;
-      statreg = tid < kKvQ ? lsebase[qr] * kLog2e : dltbase[qr];
+      qr = qr < 0 ? 0 : qr;
+      const float* sp = (tid & kKvQ) ? dltbase : lsebase;
+      statreg = sp[qr];
     }
   };
   auto write_tile = [&](int buf) {
@@ -335,7 +354,8 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
       lds_write128<T>(smem + (2 + buf) * kKvTileBytes + o, doreg[i]);
     }
     if (tid < 2 * kKvQ)
-      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) = statreg;
+      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) =
+          tid < kKvQ ? statreg * kLog2e : statreg;
   };
 
   int aoff[8];
@@ -356,10 +376,9 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-  if (jt0 < jt1) {
-    load_tile(jt0);
-    write_tile(0);
-  }
+  load_tile(jt0);          // unconditional (rows clamped): one path into the loop, see rfa_fwd.hip
+  write_tile(0);
+  wait_all_vmem();
   __syncthreads();
 
   for (int j = jt0; j < jt1; ++j) {
@@ -378,53 +397,89 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        // per-row statistics of this sub-tile: rows rq..rq+3 for jj = 0..3 (issued early)
+        f32x4 l2v[4], dlv[4];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          vec8<T> a = lds_read128<T>(qb + t * 32 * kRowBytes + aoff[kk]);
-          s = mfma(a, kf[kk], s);
+        for (int jj = 0; jj < 4; ++jj) {
+          const int rq = 32 * t + 8 * jj + 4 * g;
+          l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(st + rq * 4);
+          dlv[jj] = *(__attribute__((address_space(3))) f32x4*)(st + (kKvQ + rq) * 4);
         }
+        {
+          // S = Q K_w^T and dP = dO V_w^T as one 16-step pipeline, A fragments read kAhead ahead
+          constexpr int kAhead = 4;
+          vec8<T> a[16];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          vec8<T> a = lds_read128<T>(dob + t * 32 * kRowBytes + aoff[kk]);
-          dp = mfma(a, vf[kk], dp);
+          for (int i = 0; i < kAhead; ++i)
+            a[i] = lds_read128<T>((i < 8 ? qb : dob) + t * 32 * kRowBytes + aoff[i & 7]);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i + kAhead < 16)
+              a[i + kAhead] = lds_read128<T>(((i + kAhead) < 8 ? qb : dob) + t * 32 * kRowBytes + aoff[(i + kAhead) & 7]);
+            if (i < 8) s = mfma(a[i], kf[i], s);
+            else dp = mfma(a[i], vf[i - 8], dp);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 8 + kAhead, 0);   // 8 stat reads + first fragments
+#pragma unroll
+          for (int i = 0; i < 16 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
         }
         const bool need_mask = (qs0 + 32 > lq) || (p.causal && qs0 + off < kw0 + 31);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int rq = 32 * t + 8 * jj + 4 * g;      // rows rq .. rq+3 of the tile
-          const f32x4 l2v = *(__attribute__((address_space(3))) f32x4*)(st + rq * 4);
-          const f32x4 dlv = *(__attribute__((address_space(3))) f32x4*)(st + (kKvQ + rq) * 4);
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * jj + e;
-            float pv = fast_exp2(__builtin_fmaf(s[r], c, -l2v[e]));
-            if (need_mask) {
-              const int q = qt0 + rq + e;
-              const bool ok = (q < lq) && (!p.causal || krow <= q + off);
-              pv = ok ? pv : 0.f;
-            }
-            s[r] = pv;
-            dp[r] = pv * (dp[r] - dlv[e]);
+            s[r] = fast_exp2(__builtin_fmaf(s[r], c, -l2v[jj][e]));
+          }
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int q = qs0 + crow(r, g);
+            const bool ok = (q < lq) && (!p.causal || krow <= q + off);
+            s[r] = ok ? s[r] : 0.f;
           }
         }
 #pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          const vec8<T> pb = pack8<T>(s, 8 * ks2);
-          const vec8<T> dsb = pack8<T>(dp, 8 * ks2);
-          lds_t* dot = dob + (32 * t + 16 * ks2) * kRowBytes;
-          lds_t* qt = qb + (32 * t + 16 * ks2) * kRowBytes;
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-          for (int dblk = 0; dblk < 4; ++dblk) {
-            vec4<T> lo = lds_read_tr<T>(dot + toff[dblk][0]);
-            vec4<T> hi = lds_read_tr<T>(dot + toff[dblk][1]);
-            dv[dblk] = mfma(concat<T>(lo, hi), pb, dv[dblk]);
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * jj + e;
+            dp[r] = s[r] * (dp[r] - dlv[jj][e]);
           }
+        {
+          // dV^T += dO^T P  and  dK^T += Q^T dS : 16 MFMAs, each fed by two transpose reads
+          const vec8<T> pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 8);
+          const vec8<T> ds0 = pack8<T>(dp, 0), ds1 = pack8<T>(dp, 8);
+          constexpr int kAhead = 2;
+          vec8<T> a[16];
+          auto frag = [&](int i) {
+            // i: [ks2 (1 bit)][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk (2 bits)]
+            const int ks2 = i >> 3, which = (i >> 2) & 1, dblk = i & 3;
+            lds_t* base = (which ? qb : dob) + (32 * t + 16 * ks2) * kRowBytes;
+            vec4<T> lo = lds_read_tr<T>(base + toff[dblk][0]);
+            vec4<T> hi = lds_read_tr<T>(base + toff[dblk][1]);
+            return concat<T>(lo, hi);
+          };
 #pragma unroll
-          for (int dblk = 0; dblk < 4; ++dblk) {
-            vec4<T> lo = lds_read_tr<T>(qt + toff[dblk][0]);
-            vec4<T> hi = lds_read_tr<T>(qt + toff[dblk][1]);
-            dk[dblk] = mfma(concat<T>(lo, hi), dsb, dk[dblk]);
+          for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (i + kAhead < 16) a[i + kAhead] = frag(i + kAhead);
+            const int ks2 = i >> 3, which = (i >> 2) & 1, dblk = i & 3;
+            if (which == 0) dv[dblk] = mfma(a[i], ks2 ? pb1 : pb0, dv[dblk]);
+            else dk[dblk] = mfma(a[i], ks2 ? ds1 : ds0, dk[dblk]);
           }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
+#pragma unroll
+          for (int i = 0; i < 16 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
         }
       }
     }
@@ -441,7 +496,7 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int d0 = 32 * dblk + 8 * jj + 4 * g;
-      if (d0 < p.D) {
+      if (kFullD || d0 < p.D) {
         f32x4 x, y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -454,37 +509,41 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
     }
 }
 
-template <typename T>
+template <typename T, bool kFullD>
 static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dq_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSmem);
+    (void)hipFuncSetAttribute((const void*)dq_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSmem);
     attr_done = true;
   }
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL(dq_kernel<T>, dim3((unsigned)nblocks), dim3(kDqThreads), kDqSmem, stream, p);
+  hipLaunchKernelGGL((dq_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kDqThreads), kDqSmem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <typename T>
+template <typename T, bool kFullD>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dkdv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kKvSmem);
+    (void)hipFuncSetAttribute((const void*)dkdv_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize, kKvSmem);
     attr_done = true;
   }
   const int64_t nblocks = (int64_t)p.nkblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL(dkdv_kernel<T>, dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
+  hipLaunchKernelGGL((dkdv_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_dq_t<bf16_t>(p, stream) : launch_dq_t<f16_t>(p, stream);
+  const bool full = p.D == kHeadDim;
+  if (dtype == 0) return full ? launch_dq_t<bf16_t, true>(p, stream) : launch_dq_t<bf16_t, false>(p, stream);
+  return full ? launch_dq_t<f16_t, true>(p, stream) : launch_dq_t<f16_t, false>(p, stream);
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_dkdv_t<bf16_t>(p, stream) : launch_dkdv_t<f16_t>(p, stream);
+  const bool full = p.D == kHeadDim;
+  if (dtype == 0) return full ? launch_dkdv_t<bf16_t, true>(p, stream) : launch_dkdv_t<bf16_t, false>(p, stream);
+  return full ? launch_dkdv_t<f16_t, true>(p, stream) : launch_dkdv_t<f16_t, false>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
 int bwd_dkdv_keys_per_block() { return kKvKeys; }

@@ -143,6 +143,12 @@ __device__ __forceinline__ SeqSpan resolve_span(const int32_t* cu, int b, int S,
   return s;
 }
 
+// s_waitcnt vmcnt(0) in the form the compiler's waitcnt scoreboard sees (gfx9 encoding:
+// vmcnt = simm16[3:0] | simm16[15:14], expcnt = [6:4], lgkmcnt = [11:8]).  Used before a
+// software-pipelined loop so that no prologue load is still "pending" at the loop header —
+// otherwise hipcc's in-loop waits for it also drain the loop's own prefetch loads.
+__device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

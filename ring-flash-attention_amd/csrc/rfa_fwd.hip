@@ -25,7 +25,7 @@ constexpr int kFwdKV = 64;                  // keys per tile
 constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB
 constexpr int kFwdSmem = 4 * kFwdTileBytes;                 // K[2] + V[2] = 64 KiB
 
-template <typename T>
+template <typename T, bool kFullD>
 __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     const int d0 = 16 * kk + 8 * g;
-    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+    qf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
   }
 
   // ---- KV range of this workgroup
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   // ---- staging assignment: thread -> chunk c of rows r0, r0+32
   const int sc = tid & 15;
   const int sr = tid >> 4;
-  const bool sd_ok = sc * 8 < p.D;
+  const bool sd_ok = kFullD || sc * 8 < p.D;
   vec8<T> kreg[2], vreg[2];
 
   auto load_tile = [&](int j) {
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     for (int i = 0; i < 2; ++i) {
       int kr = j * kFwdKV + sr + 32 * i;
       kr = kr < lk ? kr : lk - 1;
+      kr = kr < 0 ? 0 : kr;
       if (sd_ok) {
         kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
         vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
@@ -135,10 +136,14 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
-  if (ntiles > 0) {
-    load_tile(0);
-    write_tile(0);
-  }
+  // Always stage tile 0 (rows are clamped, so this is safe even when ntiles == 0): keeping the
+  // prologue unconditional leaves ONE path into the loop, on which every earlier global load
+  // (Q fragment included) has provably landed — otherwise hipcc's waitcnt pass merges the
+  // "nothing waited yet" path into the loop header and drains the tile prefetch (vmcnt(0))
+  // in front of the first MFMA of every tile.
+  load_tile(0);
+  write_tile(0);
+  wait_all_vmem();          // Q fragment loads too: nothing may stay pending into the loop
   __syncthreads();
 
   for (int j = 0; j < ntiles; ++j) {
@@ -153,14 +158,29 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       // ---------------- S^T = K Q^T ----------------
       f32x16 s[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      {
+        // 16 K fragments (2 sub-tiles x 8 k-steps), read 4 ahead of their MFMA
+        constexpr int kAhead = 4;
+        vec8<T> a[16];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          vec8<T> a = lds_read128<T>(kb + t * 32 * kRowBytes + koff[kk]);
-          s[t] = mfma(a, qf[kk], s[t]);
+        for (int i = 0; i < kAhead; ++i) a[i] = lds_read128<T>(kb + (i >> 3) * 32 * kRowBytes + koff[i & 7]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i + kAhead < 16)
+            a[i + kAhead] = lds_read128<T>(kb + ((i + kAhead) >> 3) * 32 * kRowBytes + koff[(i + kAhead) & 7]);
+          s[i >> 3] = mfma(a[i], qf[i & 7], s[i >> 3]);
         }
+        // pin the issue order: kAhead reads, then read/MFMA pairs, then the MFMA tail
+        __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+        for (int i = 0; i < 16 - kAhead; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
       }
       // ---------------- mask ----------------
       const bool need_mask = (kt0 + kFwdKV > lk) || (p.causal && kt0 + kFwdKV - 1 > qw0 + off);
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (d0 < p.D) {
+        if (kFullD || d0 < p.D) {
           f32x4 x;
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
-          if (d0 < p.D) {
+          if (kFullD || d0 < p.D) {
             f32x4 x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
@@ -276,7 +296,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
-          if (d0 < p.D) {
+          if (kFullD || d0 < p.D) {
             f32x4 x = *(f32x4*)(ab + d0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = x[e] * wo + o[dblk][4 * jj + e] * wb;
@@ -288,22 +308,24 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   }
 }
 
-template <typename T>
+template <typename T, bool kFullD>
 static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)fwd_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kFwdSmem);
     attr_done = true;
   }
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL(fwd_kernel<T>, dim3((unsigned)nblocks), dim3(kFwdThreads), kFwdSmem, stream, p);
+  hipLaunchKernelGGL((fwd_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kFwdThreads), kFwdSmem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_fwd_t<bf16_t>(p, stream) : launch_fwd_t<f16_t>(p, stream);
+  const bool full = p.D == kHeadDim;
+  if (dtype == 0) return full ? launch_fwd_t<bf16_t, true>(p, stream) : launch_fwd_t<bf16_t, false>(p, stream);
+  return full ? launch_fwd_t<f16_t, true>(p, stream) : launch_fwd_t<f16_t, false>(p, stream);
 }
 
 int fwd_qrows_per_block() { return kFwdQRows; }

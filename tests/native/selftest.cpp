@@ -681,8 +681,8 @@ int main(int argc, char** argv) {
   run_bwd_acc_case(300, 3, 3, 128, 904);
 
   if (perf) {
-    run_perf(8192, 32, 8, 128, 5);
-    run_perf(8192, 32, 32, 128, 5);
+    run_perf(8192, 32, 8, 128, 20);
+    run_perf(8192, 32, 32, 128, 20);
   }
   printf("%s (%d failing groups)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
   return g_fail ? 1 : 0;
