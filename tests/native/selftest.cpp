@@ -541,8 +541,11 @@ static void run_perf(int S, int H, int Hk, int D, int iters) {
   ba.B = 1; ba.H = H; ba.Hk = Hk; ba.D = D; ba.Sq = S; ba.Sk = S; ba.total_k = S; ba.softmax_scale = scale; ba.causal = 1;
   ba.dtype = RFA_BF16;
   void* ws = nullptr;
-  const int64_t wsb = rfa_bwd_workspace_bytes(&ba);
-  if (wsb) HIPCHECK(hipMalloc(&ws, wsb));
+  {
+    rfa_bwd_args b3 = ba; b3.phases = RFA_BWD_COMPUTE;   // phased calls always need the workspace
+    const int64_t wsb = rfa_bwd_workspace_bytes(&b3);
+    if (wsb) HIPCHECK(hipMalloc(&ws, wsb));
+  }
   ba.workspace = ws;
 
   hipEvent_t e0, e1;
@@ -564,6 +567,13 @@ static void run_perf(int S, int H, int Hk, int D, int iters) {
   };
   float tf = timeit("fwd", fwd_flop, [&] { if (rfa_fwd(&fa, nullptr)) { printf("fwd err\n"); exit(3); } });
   float tp = timeit("bwd-pre", 0.0, [&] { rfa_bwd_preprocess(&pa, nullptr); });
+  {
+    rfa_bwd_args b2 = ba;
+    b2.phases = RFA_BWD_COMPUTE | RFA_BWD_SKIP_DKDV;
+    timeit("bwd:dq", 0.5 * fwd_flop, [&] { rfa_bwd(&b2, nullptr); });
+    b2.phases = RFA_BWD_COMPUTE | RFA_BWD_SKIP_DQ;
+    timeit("bwd:dkdv", 2.0 * fwd_flop, [&] { rfa_bwd(&b2, nullptr); });
+  }
   float tb = timeit("bwd", 2.5 * fwd_flop, [&] { if (rfa_bwd(&ba, nullptr)) { printf("bwd err\n"); exit(3); } });
   const float tot = tf + tp + tb;
   printf("    fwd+bwd      %8.3f ms   %8.1f it/s   %8.1f TFLOP/s   %.1f%% of 2.5 PF\n", tot, 1000.f / tot,
@@ -646,14 +656,20 @@ static void run_perf(int S, int H, int Hk, int D, int iters) {
 }
 
 int main(int argc, char** argv) {
-  bool perf = false, quick = false;
+  bool perf = false, quick = false, perf_only = false;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--perf")) perf = true;
     if (!strcmp(argv[i], "--quick")) quick = true;
+    if (!strcmp(argv[i], "--perf-only")) perf = perf_only = true;
   }
   hipDeviceProp_t prop;
   HIPCHECK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s (%s), %d CUs, abi %d\n", prop.name, prop.gcnArchName, prop.multiProcessorCount, rfa_abi_version());
+  if (perf_only) {
+    run_perf(8192, 32, 8, 128, 20);
+    printf("%s (%d failing groups)\n", g_fail ? "SELFTEST FAILED" : "SELFTEST PASSED", g_fail);
+    return g_fail ? 1 : 0;
+  }
   run_probes();
 
   std::vector<Case> cases = {
