@@ -7,7 +7,7 @@ Keeps the three entry points of /root/reference/ring_flash_attn/adapters/hf_adap
 and the same per-micro-batch protocol (README.md:15-68 of the reference):
 
     substitute_hf_flash_attn(group, heads_k_stride=1)         # once
-    model = AutoModelForCausalLM.from_config(cfg, attn_implementation="ring_flash_attn")
+    model = AutoModelForCausalLM.from_config(cfg, attn_implementation="ring_attn")
     update_ring_flash_attn_params(cu_seqlens, group)           # per micro-batch (global cu_seqlens)
     model(input_ids=local_chunk, position_ids=local_positions)
 
@@ -16,7 +16,7 @@ Re-targeted to transformers >= 4.48 / 5.x, where attention implementations are l
 no longer exist in transformers 5 — `_flash_supports_window_size`, `is_flash_attn_greater_or_equal`,
 hf_adapter.py:9-19 — and `attn_implementation="flash_attention_2"` refuses to load without the
 CUDA `flash_attn` wheel).  The adapter therefore registers its own implementation name,
-"ring_flash_attn", and — for parity with hf_adapter.py:392-393 — also takes over the
+"ring_attn", and — for parity with hf_adapter.py:392-393 — also takes over the
 "flash_attention_2" slot and the module-level `_flash_attention_forward` hook.
 """
 import os
@@ -30,7 +30,9 @@ from ..llama3_flash_attn_varlen import (
     llama3_flash_attn_prepare_cu_seqlens,
 )
 
-ATTN_IMPLEMENTATION = "ring_flash_attn"
+# NB: the name must not contain "flash": transformers 5.x treats any such name as a flash-attention
+# kernel request and tries to import the CUDA `flash_attn` package / a hub kernel for it.
+ATTN_IMPLEMENTATION = "ring_attn"
 
 DATA_PARAMS = {}
 RING_ATTN_SWITCH = True

@@ -1,0 +1,99 @@
+"""Worker for the HF-adapter tests (BASELINE config 5 shape family): a random-init Qwen3 runs on a
+packed batch sharded over W ranks through `substitute_hf_flash_attn` / `update_ring_flash_attn_params`
+(README.md:15-68 of the reference) and is compared with the same model run on each whole sequence
+with transformers' eager attention in a single process (logits and parameter gradients)."""
+import os
+import sys
+import traceback
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "ring-flash-attention_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def build_model(cfg_kw, attn_impl, dtype, device):
+    from transformers import AutoConfig, AutoModelForCausalLM
+
+    torch.manual_seed(0)
+    cfg = AutoConfig.for_model("qwen3", **cfg_kw)
+    model = AutoModelForCausalLM.from_config(cfg, attn_implementation=attn_impl)
+    return model.to(device=device, dtype=dtype)
+
+
+def make_batch(cu, vocab):
+    g = torch.Generator().manual_seed(7)
+    T = cu[-1]
+    ids = torch.randint(0, vocab, (T,), generator=g)
+    pos = torch.cat([torch.arange(b - a) for a, b in zip(cu[:-1], cu[1:])])
+    w = torch.randn(T, generator=g)          # per-token loss weights
+    return ids, pos, w
+
+
+def reference(cfg_kw, cu, dtype, device):
+    """single process, eager attention, one sequence at a time"""
+    model = build_model(cfg_kw, "eager", dtype, device)
+    ids, pos, w = make_batch(cu, cfg_kw["vocab_size"])
+    logits = []
+    loss = 0.0
+    for a, b in zip(cu[:-1], cu[1:]):
+        out = model(input_ids=ids[None, a:b].to(device), position_ids=pos[None, a:b].to(device)).logits[0]
+        logits.append(out)
+        loss = loss + (out.float().sum(-1) * w[a:b].to(device)).sum()
+    loss.backward()
+    grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+    return torch.cat(logits).detach().float().cpu(), grads
+
+
+def run_rank(rank, W, port, cfg_kw, cu, use_hip, heads_k_stride, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=W)
+        from ring_flash_attn import backend, substitute_hf_flash_attn, update_ring_flash_attn_params
+        from ring_flash_attn.adapters.hf_adapter import ATTN_IMPLEMENTATION
+
+        if use_hip:
+            dev, dtype = torch.device("cuda:0"), torch.bfloat16
+            torch.cuda.set_device(dev)
+            backend.set_backend(None)
+        else:
+            from oracle.oracle_backend import OracleBackend
+
+            dev, dtype = torch.device("cpu"), torch.float32
+            backend.set_backend(OracleBackend())
+        substitute_hf_flash_attn(None, heads_k_stride)
+        model = build_model(cfg_kw, ATTN_IMPLEMENTATION, dtype, dev)
+        ids, pos, w = make_batch(cu, cfg_kw["vocab_size"])
+        L = cu[-1] // W
+        sl = slice(rank * L, (rank + 1) * L)
+        update_ring_flash_attn_params(torch.tensor(cu, dtype=torch.int32, device=dev), None)
+        logits = model(input_ids=ids[None, sl].to(dev), position_ids=pos[None, sl].to(dev)).logits[0]
+        loss = (logits.float().sum(-1) * w[sl].to(dev)).sum()
+        loss.backward()
+        grads = {}
+        for n, p in model.named_parameters():
+            g = p.grad.detach().float().cpu()
+            dist.all_reduce(g)
+            grads[n] = g
+        ret[rank] = dict(logits=logits.detach().float().cpu(), grads=grads if rank == 0 else None)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        ret[rank] = dict(error=traceback.format_exc())
+
+
+def run_world(W, cfg_kw, cu, use_hip, heads_k_stride, port):
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(run_rank, args=(W, port, cfg_kw, cu, use_hip, heads_k_stride, ret), nprocs=W, join=True)
+    outs = [ret[r] for r in range(W)]
+    for o in outs:
+        if "error" in o:
+            raise RuntimeError(o["error"])
+    return torch.cat([o["logits"] for o in outs]), outs[0]["grads"]

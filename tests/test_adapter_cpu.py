@@ -1,0 +1,37 @@
+"""HF adapter (SURVEY §8 row "HF adapter boundary", BASELINE config 5 family) on CPU: a random-init
+Qwen3 sharded over 2 gloo ranks through substitute_hf_flash_attn / update_ring_flash_attn_params,
+with the CPU oracle as operator backend, must reproduce the single-process eager model (logits and
+all parameter gradients).  Checks the adapter wiring + llama3 all-gather / reduce-scatter schedule."""
+import pytest
+import torch
+
+from conftest import free_port
+import _adapter_worker as AW
+
+CFG = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+           num_key_value_heads=2, head_dim=16, vocab_size=128, max_position_embeddings=256)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_qwen3_ring_adapter_matches_eager(stride):
+    cu = [0, 23, 70, 96]                       # deliberately not rank aligned
+    ref_logits, ref_grads = AW.reference(CFG, cu, torch.float32, torch.device("cpu"))
+    logits, grads = AW.run_world(2, CFG, cu, use_hip=False, heads_k_stride=stride, port=free_port())
+    assert logits.shape == ref_logits.shape
+    assert (logits - ref_logits).abs().max() < 2e-4 * max(1.0, ref_logits.abs().max().item())
+    for n, g in ref_grads.items():
+        assert (grads[n] - g).abs().max() <= 5e-4 * max(1.0, g.abs().max().item()), n
+
+
+def test_use_ring_attn_switch_and_param_guard(single_rank_group):
+    from ring_flash_attn.adapters import hf_adapter as A
+
+    A.DATA_PARAMS.clear()
+    q = torch.zeros(1, 4, 2, 8)
+    with pytest.raises(RuntimeError, match="update_ring_flash_attn_params"):
+        A._ring_attention(q, q, q, dropout=0.0, softmax_scale=None, causal=True)
+    with pytest.raises(AssertionError):
+        A._ring_attention(q, q, q, dropout=0.0, softmax_scale=None, causal=False)
+    A.use_ring_attn(False)
+    assert A.RING_ATTN_SWITCH is False
+    A.use_ring_attn(True)
