@@ -93,14 +93,18 @@ def test_config5_hf_adapter_qwen3_w2():
                num_key_value_heads=8, head_dim=128, vocab_size=4096, max_position_embeddings=8192)
     cu = [0, 750, 2250, 4096]                   # not rank aligned (as SURVEY §8d cfg 5, scaled)
     dev = torch.device("cuda:0")
-    # reference: same bf16 model on the same GPU, transformers' eager attention, sequence by sequence
-    ref_logits, ref_grads = AW.reference(cfg, cu, torch.bfloat16, dev)
+    # flash-attention style criterion: against an fp32 eager reference of the same model,
+    # the bf16 ring model may be at most 2x as far off as the bf16 eager model (+ a small floor)
+    ref_logits, ref_grads = AW.reference(cfg, cu, torch.float32, dev)
+    bf_logits, bf_grads = AW.reference(cfg, cu, torch.bfloat16, dev)
     torch.cuda.empty_cache()
     logits, grads = AW.run_world(2, cfg, cu, use_hip=True, heads_k_stride=1, port=free_port())
     scale = ref_logits.abs().max().item()
-    assert (logits - ref_logits).abs().max().item() <= 3e-2 * scale + 2e-2
-    worst = 0.0
+    e_ring = (logits - ref_logits).abs().max().item()
+    e_bf = (bf_logits - ref_logits).abs().max().item()
+    assert e_ring <= 2 * e_bf + 1e-2 * scale, f"logits: ring {e_ring:.3e} vs eager-bf16 {e_bf:.3e}"
     for n, g in ref_grads.items():
         denom = max(g.abs().max().item(), 1e-3)
-        worst = max(worst, (grads[n] - g).abs().max().item() / denom)
-    assert worst < 8e-2, f"worst relative grad error {worst:.3e}"
+        er = (grads[n] - g).abs().max().item() / denom
+        eb = (bf_grads[n] - g).abs().max().item() / denom
+        assert er <= 2 * eb + 2e-2, f"{n}: ring {er:.3e} vs eager-bf16 {eb:.3e}"
