@@ -16,6 +16,19 @@
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
 
+// ---- tuning knobs (A/B'd on hardware with tools/ab_variants.py; defaults = best measured) ----
+#ifndef RFA_FWD_PRIO
+#define RFA_FWD_PRIO 0       // 1: s_setprio(1) around MFMA clusters; 2: static priority for waves 4-7
+#endif
+#ifndef RFA_FWD_DEFER
+#define RFA_FWD_DEFER 8      // >0: skip the O/l rescale while the row max grew by <= this many log2 units
+                             // (A/B: 0 -> 0.676 ms, 4 -> 0.648 ms, 8 -> 0.635 ms; accuracy unchanged, see the
+                             //  'spike keys' self-test cases that force the rescale branch mid-loop)
+#endif
+#ifndef RFA_FWD_AHEAD
+#define RFA_FWD_AHEAD 4
+#endif
+
 namespace rfa {
 
 constexpr int kFwdWaves = 8;
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   write_tile(0);
   wait_all_vmem();          // Q fragment loads too: nothing may stay pending into the loop
   __syncthreads();
+  if (RFA_FWD_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   for (int j = 0; j < ntiles; ++j) {
     const int buf = j & 1;
@@ -161,9 +175,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
       {
-        // 16 K fragments (2 sub-tiles x 8 k-steps), read 4 ahead of their MFMA
-        constexpr int kAhead = 4;
+        // 16 K fragments (2 sub-tiles x 8 k-steps), read kAhead ahead of their MFMA
+        constexpr int kAhead = RFA_FWD_AHEAD;
         vec8<T> a[16];
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) a[i] = lds_read128<T>(kb + (i >> 3) * 32 * kRowBytes + koff[i & 7]);
@@ -182,6 +197,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
       }
+      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       // ---------------- mask ----------------
       const bool need_mask = (kt0 + kFwdKV > lk) || (p.causal && kt0 + kFwdKV - 1 > qw0 + off);
       if (need_mask) {
@@ -202,10 +218,22 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
       mloc = fmaxf(mloc, shfl_xor32(mloc));
       const float mnew = fmaxf(m, mloc);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float alpha = fast_exp2(m * c - msafe * c);
-      m = mnew;
-      const float mc = msafe * c;
+      // deferred rescale (RFA_FWD_DEFER > 0): while no row of the wave grew its max by more than
+      // DEFER log2 units, keep the stale max — P is then bounded by 2^DEFER instead of 1, still
+      // exact in fp32 / same relative precision in bf16 — and skip the 64-register O rescale.
+      bool rescale = true;
+      if (RFA_FWD_DEFER > 0) rescale = !__all((mnew - m) * c <= (float)RFA_FWD_DEFER);
+      if (rescale) {
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = fast_exp2(m * c - msafe * c);
+        m = mnew;
+        lsum *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mc = ((m == -INFINITY) ? 0.f : m) * c;
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -215,13 +243,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
           s[t][r] = pv;
           psum += pv;
         }
-      lsum = lsum * alpha + psum;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      lsum += psum;
 
       // ---------------- O^T += V^T P^T ----------------
+      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -235,6 +260,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
             o[dblk] = mfma(concat<T>(lo, hi), pb, o[dblk]);
           }
         }
+      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
     if (j + 1 < ntiles) write_tile(buf ^ 1);
     __syncthreads();

@@ -192,6 +192,9 @@ struct Case {
   int B, H, Hk, D, Sq, Sk, causal;
   std::vector<int> cu;     // non-empty => varlen with cu_q == cu_k == cu (B = cu.size()-1)
   std::vector<int> cuk;    // optional distinct cu_k
+  int spike = 0;           // >0: plant keys k[j] = 3*q[i] so single rows' maxima jump by >> 8 log2
+                           // units at chosen tiles (forces the rare deferred-rescale branch of the
+                           // online softmax in the middle of the K loop; dense, H == Hk only)
 };
 
 struct ErrStat { double maxerr = 0, maxref = 0; size_t nan = 0; };
@@ -242,6 +245,19 @@ static void run_case(const Case& c, uint64_t seed) {
   fill_normal(k, kf, (size_t)Tk * Hk * D, r);
   fill_normal(v, vf, (size_t)Tk * Hk * D, r);
   fill_normal(dout, dof, (size_t)Tq * H * D, r);
+  if (c.spike && !varlen && H == Hk) {
+    // (query row, key row) pairs spread over first / middle / last KV tiles and both sub-tiles
+    const int pairs[][2] = {{5, 70}, {40, 3}, {100, Sk - 1}, {Sq - 1, Sk / 2 + 1}, {Sq / 2, 130}, {17, 200 % Sk}};
+    for (auto& pr : pairs) {
+      const int i = pr[0] % Sq, j = pr[1] % Sk;
+      for (int h = 0; h < H; ++h)
+        for (int d = 0; d < D; ++d) {
+          const size_t qi = ((size_t)i * H + h) * D + d, kj = ((size_t)j * Hk + h) * D + d;
+          k[kj] = f2bf(3.0f * qf[qi]);
+          kf[kj] = bf2f(k[kj]);
+        }
+    }
+  }
 
   // ---- oracle
   std::vector<float> ro((size_t)Tq * H * D), rl((size_t)Tq * H), rdq((size_t)Tq * H * D),
@@ -686,6 +702,8 @@ int main(int argc, char** argv) {
       {"varlen ref fixture/8", 0, 5, 5, 128, 0, 0, 1, {0, 16, 156, 530}, {}},
       {"varlen noncausal", 0, 4, 2, 128, 0, 0, 0, {0, 120, 1248, 1500}, {}},
       {"varlen q!=k (llama3 style)", 0, 4, 2, 128, 0, 0, 1, {0, 100, 356}, {0, 300, 812}},
+      {"spike keys, non-causal (forces mid-loop rescale)", 1, 2, 2, 128, 300, 520, 0, {}, {}, 1},
+      {"spike keys, causal", 1, 3, 3, 128, 640, 640, 1, {}, {}, 1},
   };
   if (quick) cases.resize(4);
   uint64_t seed = 100;
