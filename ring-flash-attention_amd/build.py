@@ -9,6 +9,7 @@ Targets (all in-tree, so the artefacts travel with the repo snapshot to the GPU 
 `python ring-flash-attention_amd/build.py [lib] [oracle] [selftest] [--force]`
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -35,11 +36,27 @@ def _hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build librfa_hip.so)")
 
 
-def _stale(target, sources):
-    if not os.path.exists(target):
+def _digest(sources, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for s in sources:
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(target, sources, extra=""):
+    """Content-hash staleness (a `<target>.srchash` sidecar), NOT mtimes: repo snapshots copied to
+    the GPU box do not preserve mtime order, and a spurious rebuild there would overwrite a shared
+    library that the running test process has already mapped."""
+    side = target + ".srchash"
+    if not os.path.exists(target) or not os.path.exists(side):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in sources)
+    return open(side).read().strip() != _digest(sources, extra)
+
+
+def _stamp(target, sources, extra=""):
+    with open(target + ".srchash", "w") as f:
+        f.write(_digest(sources, extra))
 
 
 def _run(cmd, cwd=None):
@@ -58,21 +75,24 @@ def build_lib(force=False):
     cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
     cmd += ["-o", LIB]
     _run(cmd)
+    _stamp(LIB, deps)
     return LIB
 
 
 def build_oracle(force=False):
     if not force and not _stale(ORACLE_LIB, [ORACLE_SRC]):
         return ORACLE_LIB
-    _run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", ORACLE_SRC,
+    _run(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c11", ORACLE_SRC,
           "-o", ORACLE_LIB, "-lm"])
+    _stamp(ORACLE_LIB, [ORACLE_SRC])
     return ORACLE_LIB
 
 
 def build_selftest(force=False):
     build_lib(force)
     build_oracle(force)
-    deps = [SELFTEST_SRC, LIB, ORACLE_LIB, os.path.join(CSRC, "rfa_common.hpp")]
+    # the binary only depends on these sources + the two libraries' *interfaces*
+    deps = [SELFTEST_SRC, os.path.join(CSRC, "rfa_common.hpp"), os.path.join(ROOT, "include", "rfa.h"), ORACLE_SRC]
     if not force and not _stale(SELFTEST_BIN, deps):
         return SELFTEST_BIN
     _run([_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value",
@@ -80,6 +100,7 @@ def build_selftest(force=False):
           "-L" + os.path.dirname(LIB), "-lrfa_hip", "-L" + os.path.dirname(ORACLE_LIB), "-lattn_ref",
           "-Wl,-rpath,$ORIGIN/../../ring-flash-attention_amd/ring_flash_attn",
           "-Wl,-rpath,$ORIGIN/../../oracle"])
+    _stamp(SELFTEST_BIN, deps)
     return SELFTEST_BIN
 
 

@@ -68,8 +68,87 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
     return _Fn
 
 
-def make_dense_api(fn, prefix):
+def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pack_dim, n_packed):
+    """autograd Function for the packed entry points (`kv` = 2 tensors, `qkv` = 3 tensors stacked on
+    `pack_dim`).  Same math as `base_fn`; the only difference is where the gradients land: ONE packed
+    buffer whose slices are handed to the schedule as output views (`out_grads`), instead of letting
+    autograd build the packed gradient from three slice-gradients (zero-fill + copy + add kernels
+    per step).  Falls back to the generic path when the schedule returns fresh tensors (W > 1)."""
+
+    class _PFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, *args):
+            n_t = 1 if n_packed == 3 else 2                 # (qkv,) or (q, kv)
+            tensors, rest = args[:n_t], args[n_t:]
+            packed = tensors[-1]
+            parts = [packed.select(pack_dim, i) for i in range(n_packed)]
+            q, k, v = (parts if n_packed == 3 else [tensors[0]] + parts)
+            lead = rest[:n_lead]
+            (dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic,
+             return_softmax, group) = rest[n_lead:]
+            if softmax_scale is None:
+                softmax_scale = q.shape[-1] ** (-0.5)
+            _check_unsupported(dropout_p, window_size, alibi_slopes)
+            q, k, v = _prep_qkv(q, k, v, group)
+            tensors_lead = ()
+            if n_lead:
+                cu = _as_cu(lead[0], q.device)
+                lead = (cu,) + tuple(lead[1:])
+                tensors_lead = (cu,)
+            out, softmax_lse = forward_impl(
+                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+            )
+            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
+            ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
+            ctx.softmax_scale = softmax_scale
+            ctx.causal = causal
+            ctx.deterministic = deterministic
+            ctx.group = group
+            ctx.packed_meta = (packed.shape, packed.dtype, packed.device)
+            return out if not return_softmax else (out, softmax_lse, None)
+
+        @staticmethod
+        def backward(ctx, dout, *args):
+            q, k, v, out, softmax_lse, *tensors_lead = ctx.saved_tensors
+            shape, dtype, device = ctx.packed_meta
+            dpacked = torch.empty(shape, dtype=dtype, device=device)
+            views = [dpacked.select(pack_dim, i) for i in range(n_packed)]
+            if n_packed == 3:
+                out_grads = tuple(views)
+            else:
+                out_grads = (None, views[0], views[1])
+            dq, dk, dv = backward_impl(
+                ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
+                softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
+                window_size=(-1, -1), alibi_slopes=None, deterministic=ctx.deterministic,
+                out_grads=out_grads,
+            )
+            got = (dq, dk, dv)[3 - n_packed:]
+            for view, g in zip(views, got):
+                if g.data_ptr() != view.data_ptr():       # schedule returned its own tensor (W > 1)
+                    view.copy_(g)
+            grads = (dpacked,) if n_packed == 3 else (dq, dpacked)
+            return grads + (None,) * (n_lead + 8)
+
+    _PFn.__name__ = _PFn.__qualname__ = name
+    return _PFn
+
+
+def _grad_buffers(out_grads, q, k, v):
+    """(dq, dk, dv) output tensors for the single-GPU path: caller-provided views or fresh."""
+    og = out_grads or (None, None, None)
+    return (og[0] if og[0] is not None else torch.empty_like(q),
+            og[1] if og[1] is not None else torch.empty_like(k),
+            og[2] if og[2] is not None else torch.empty_like(v))
+
+
+def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None):
     """(B,S,H,D) API: returns (func, kvpacked_func, qkvpacked_func)."""
+    kv_fn = qkv_fn = None
+    if forward_impl is not None:
+        kv_fn = make_packed_function(fn.__name__ + "KVPacked", fn, forward_impl, backward_impl, 0, 2, 2)
+        qkv_fn = make_packed_function(fn.__name__ + "QKVPacked", fn, forward_impl, backward_impl, 0, 2, 3)
 
     def func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
              alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
@@ -78,11 +157,17 @@ def make_dense_api(fn, prefix):
 
     def kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                       alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        if kv_fn is not None:
+            return kv_fn.apply(q, kv, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
+                               deterministic, return_attn_probs, group)
         return fn.apply(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal, window_size,
                         alibi_slopes, deterministic, return_attn_probs, group)
 
     def qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                        alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        if qkv_fn is not None:
+            return qkv_fn.apply(qkv, dropout_p, softmax_scale, causal, window_size, alibi_slopes,
+                                deterministic, return_attn_probs, group)
         return fn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal,
                         window_size, alibi_slopes, deterministic, return_attn_probs, group)
 

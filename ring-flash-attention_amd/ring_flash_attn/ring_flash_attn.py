@@ -12,7 +12,7 @@ import torch
 from . import _C
 from .backend import get_backend
 from .utils import RingComm
-from ._api import make_autograd_function, make_dense_api
+from ._api import make_autograd_function, make_dense_api, _grad_buffers
 
 
 def ring_flash_attn_forward(
@@ -73,6 +73,7 @@ def ring_flash_attn_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    out_grads=None,
 ):
     be = get_backend()
     kv_comm = RingComm(process_group)
@@ -87,7 +88,7 @@ def ring_flash_attn_backward(
     be.bwd_preprocess(dout, out, delta)
 
     if kv_comm.world_size == 1:
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=causal,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic)
         return dq, dk, dv
@@ -138,4 +139,4 @@ RingFlashAttnFunc = make_autograd_function(
     ring_flash_attn_func,
     ring_flash_attn_kvpacked_func,
     ring_flash_attn_qkvpacked_func,
-) = make_dense_api(RingFlashAttnFunc, "ring_flash_attn")
+) = make_dense_api(RingFlashAttnFunc, "ring_flash_attn", ring_flash_attn_forward, ring_flash_attn_backward)

@@ -22,7 +22,7 @@ import torch
 from . import _C
 from .backend import get_backend
 from .utils import RingComm
-from ._api import make_autograd_function, make_dense_api
+from ._api import make_autograd_function, make_dense_api, _grad_buffers
 
 
 def zigzag_ring_flash_attn_forward(
@@ -89,6 +89,7 @@ def zigzag_ring_flash_attn_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    out_grads=None,
 ):
     assert causal == True, "zigzag ring is meaningless for causal=False"
     be = get_backend()
@@ -105,7 +106,7 @@ def zigzag_ring_flash_attn_backward(
     be.bwd_preprocess(dout, out, delta)
 
     if kv_comm.world_size == 1:
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic)
         return dq, dk, dv
@@ -166,4 +167,5 @@ ZigZagRingFlashAttnFunc = make_autograd_function(
     zigzag_ring_flash_attn_func,
     zigzag_ring_flash_attn_kvpacked_func,
     zigzag_ring_flash_attn_qkvpacked_func,
-) = make_dense_api(ZigZagRingFlashAttnFunc, "zigzag_ring_flash_attn")
+) = make_dense_api(ZigZagRingFlashAttnFunc, "zigzag_ring_flash_attn", zigzag_ring_flash_attn_forward,
+                   zigzag_ring_flash_attn_backward)
