@@ -80,11 +80,11 @@ def build_lib(force=False):
 
 
 def build_oracle(force=False):
-    if not force and not _stale(ORACLE_LIB, [ORACLE_SRC]):
+    cmd = ["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c11", ORACLE_SRC, "-o", ORACLE_LIB, "-lm"]
+    if not force and not _stale(ORACLE_LIB, [ORACLE_SRC], " ".join(cmd)):
         return ORACLE_LIB
-    _run(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-std=c11", ORACLE_SRC,
-          "-o", ORACLE_LIB, "-lm"])
-    _stamp(ORACLE_LIB, [ORACLE_SRC])
+    _run(cmd)
+    _stamp(ORACLE_LIB, [ORACLE_SRC], " ".join(cmd))
     return ORACLE_LIB
 
 
