@@ -38,6 +38,9 @@
 #ifndef RFA_KV_SPECIALIZED
 #define RFA_KV_SPECIALIZED 0  // 0: dkdv_kernel (4 waves, 512 regs) = 1.15 ms; 1: dkdv2_kernel (8 waves, role-split) = 1.26 ms
 #endif
+#ifndef RFA_KV_DMA
+#define RFA_KV_DMA 0         // 1: dkdv_kernel (D == 128) stages Q/dO with global_load_lds (47 fewer VGPRs; measured neutral: 1.183 vs 1.190 ms)
+#endif
 #ifndef RFA_KV_ILV
 #define RFA_KV_ILV 0         // 1: alternate the S / dP (and dV / dK) accumulator chains MFMA by MFMA
 #endif
@@ -376,8 +379,35 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
       lds_write128<T>(smem + (2 + buf) * kKvTileBytes + o, doreg[i]);
     }
     if (tid < 2 * kKvQ)
-      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) =
-          tid < kKvQ ? statreg * kLog2e : statreg;
+      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) = statreg;
+  };
+  // DMA staging (D == 128 only): global_load_lds writes LDS at wave-uniform base + 16*lane, i.e. one
+  // instruction fills 4 consecutive tile rows in PHYSICAL chunk order; the XOR swizzle is therefore
+  // applied to the SOURCE chunk each lane fetches.  Rows 4*(4i+wave) .. +3; swz(row) of lane l is
+  // ((l>>4)<<2) | wave for every i, so the logical chunk is a per-lane constant.
+  constexpr bool kDma = RFA_KV_DMA && kFullD;
+  const int dma_chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | wave);
+  auto dma_tile = [&](int j, int buf) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cidx = 4 * i + wave;
+      int qr = j * kKvQ + 4 * cidx + (lane >> 4);
+      qr = qr < lq ? qr : lq - 1;
+      qr = qr < 0 ? 0 : qr;
+      __builtin_amdgcn_global_load_lds((gptr_t)(qbase + (int64_t)qr * p.q_st.row + dma_chunk * 8),
+                                       (lptr_t)(smem + buf * kKvTileBytes + cidx * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(dobase + (int64_t)qr * p.dout_st.row + dma_chunk * 8),
+                                       (lptr_t)(smem + (2 + buf) * kKvTileBytes + cidx * 1024), 16, 0, 0);
+    }
+    if (wave < 2) {                                   // wave 0: lse[64], wave 1: delta[64]  (raw values)
+      int qr = j * kKvQ + lane;
+      qr = qr < lq ? qr : lq - 1;
+      qr = qr < 0 ? 0 : qr;
+      const float* sp = wave ? dltbase : lsebase;
+      __builtin_amdgcn_global_load_lds((gptr_t)(sp + qr), (lptr_t)(stat_base + buf * kKvStatBytes + wave * 256), 4, 0, 0);
+    }
   };
 
   int aoff[8];
@@ -398,8 +428,12 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-  load_tile(jt0);          // unconditional (rows clamped): one path into the loop, see rfa_fwd.hip
-  write_tile(0);
+  if (kDma) {
+    dma_tile(jt0, 0);
+  } else {
+    load_tile(jt0);        // unconditional (rows clamped): one path into the loop, see rfa_fwd.hip
+    write_tile(0);
+  }
   wait_all_vmem();
   __syncthreads();
 
@@ -408,7 +442,10 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
     lds_t* qb = smem + buf * kKvTileBytes;
     lds_t* dob = smem + (2 + buf) * kKvTileBytes;
     lds_t* st = stat_base + buf * kKvStatBytes;
-    if (j + 1 < jt1) load_tile(j + 1);
+    if (j + 1 < jt1) {
+      if (kDma) dma_tile(j + 1, buf ^ 1);   // lands in the idle buffer while this tile is computed
+      else load_tile(j + 1);
+    }
     const int qt0 = j * kKvQ;
 
     // ---- building blocks of one 32-row sub-tile t ------------------------------------------
@@ -457,7 +494,7 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -l2v[jj][e]));
+        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * l2v[jj][e]));
       if (masked) {
         const int qs0 = qt0 + 32 * t;
 #pragma unroll
@@ -542,7 +579,11 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
         }
       }
     }
-    if (j + 1 < jt1) write_tile(buf ^ 1);
+    if (kDma) {
+      wait_all_vmem();                       // this wave's DMA pieces landed; the barrier publishes all
+    } else if (j + 1 < jt1) {
+      write_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
