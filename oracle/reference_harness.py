@@ -26,6 +26,7 @@ _MODULES = [
     "ring_flash_attn_varlen",
     "zigzag_ring_flash_attn_varlen",
     "llama3_flash_attn_varlen",
+    "stripe_flash_attn",
 ]
 
 

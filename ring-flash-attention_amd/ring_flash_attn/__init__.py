@@ -31,6 +31,11 @@ from .zigzag_ring_flash_attn_varlen import (
     zigzag_ring_flash_attn_varlen_kvpacked_func,
     zigzag_ring_flash_attn_varlen_qkvpacked_func,
 )
+from .stripe_flash_attn import (
+    stripe_flash_attn_func,
+    stripe_flash_attn_kvpacked_func,
+    stripe_flash_attn_qkvpacked_func,
+)
 from .adapters import (
     substitute_hf_flash_attn,
     update_ring_flash_attn_params,

@@ -15,6 +15,21 @@ import torch
 from ._common import _prep_qkv, _as_cu
 
 
+def _opaque(fn):
+    """`torch.compile(ring_fn)` must keep working (the reference runs every test twice, eager and
+    compiled: test/test.sh:23-25).  The operators are ctypes calls into librfa_hip.so plus
+    torch.distributed traffic, which dynamo cannot trace, so the public callables are marked opaque:
+    a compiled caller graph-breaks around them and runs them eagerly, with identical results."""
+    try:
+        import functools
+
+        wrapped = torch.compiler.disable(fn)
+        functools.update_wrapper(wrapped, fn)
+        return wrapped
+    except Exception:        # very old torch without torch.compiler
+        return fn
+
+
 def _check_unsupported(dropout_p, window_size, alibi_slopes):
     assert alibi_slopes is None
     if dropout_p and dropout_p > 0:
@@ -173,7 +188,7 @@ def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None):
 
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return func, kvpacked_func, qkvpacked_func
+    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)
 
 
 def make_varlen_api(fn, prefix):
@@ -199,4 +214,4 @@ def make_varlen_api(fn, prefix):
 
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return func, kvpacked_func, qkvpacked_func
+    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)

@@ -16,7 +16,7 @@ import torch.distributed as dist
 
 from .backend import get_backend
 from .utils import AllGatherComm as Comm, reduce_scatter
-from ._api import _check_unsupported
+from ._api import _check_unsupported, _opaque
 from ._common import _as_cu
 
 
@@ -299,7 +299,7 @@ def _make_llama3_api():
     func.__name__ = func.__qualname__ = "llama3_flash_attn_varlen_func"
     kvpacked_func.__name__ = kvpacked_func.__qualname__ = "llama3_flash_attn_varlen_kvpacked_func"
     qkvpacked_func.__name__ = qkvpacked_func.__qualname__ = "llama3_flash_attn_varlen_qkvpacked_func"
-    return func, kvpacked_func, qkvpacked_func
+    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)
 
 
 (

@@ -67,6 +67,8 @@ def run_rank(rank, W, port, names, use_hip, ret):
                 out, lse, _ = R.zigzag_ring_flash_attn_func(q, k, v, causal=True, **kw)
             elif kind == "ring":
                 out, lse, _ = R.ring_flash_attn_func(q, k, v, causal=c["causal"], **kw)
+            elif kind == "stripe":
+                out, lse, _ = R.stripe_flash_attn_func(q, k, v, causal=True, **kw)
             elif kind == "zigzag_varlen":
                 out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(q, k, v, extra["cu_local"].to(dev), extra["max_local"], causal=True, **kw)
             elif kind == "ring_varlen":

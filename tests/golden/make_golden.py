@@ -10,7 +10,7 @@ Each case stores the GLOBAL seeded inputs once and, per rank, the reference's ou
 (tests re-shard the inputs with the `shard()` function of this file).  Sharding follows the
 reference tests (test/test_zigzag_ring_flash_attn_func.py:9-14, test_ring_flash_attn_func.py:36,
 test_zigzag_ring_flash_attn_varlen_func.py:9-20, test_ring_flash_attn_varlen_func.py:9-15,
-test_llama3_flash_attn_varlen_func.py:42-43).  Also stores golden outputs of
+test_llama3_flash_attn_varlen_func.py:42-43, test_stripe_flash_attn_func.py:9-14).  Also stores golden outputs of
 llama3_flash_attn_prepare_cu_seqlens (test/test_llama3_prepare_cu_seqlens.py fixture + extras).
 """
 import os
@@ -35,6 +35,8 @@ CASES = {
     "zigzag_varlen_w4_gqa": dict(kind="zigzag_varlen", W=4, cu=[0, 32, 128], H=4, Hk=2, D=32, seed=16),
     "ring_varlen_w2_causal": dict(kind="ring_varlen", W=2, cu=[0, 20, 84, 128], H=2, Hk=2, D=32, causal=True, seed=17),
     "ring_varlen_w4_noncausal": dict(kind="ring_varlen", W=4, cu=[0, 32, 128], H=4, Hk=2, D=32, causal=False, seed=18),
+    "stripe_w4": dict(kind="stripe", W=4, B=1, S=128, H=2, Hk=2, D=32, seed=21),
+    "stripe_w2_gqa": dict(kind="stripe", W=2, B=2, S=48, H=4, Hk=2, D=32, seed=22),
     "llama3_w4": dict(kind="llama3", W=4, cu=[0, 22, 75, 128], H=4, Hk=2, D=32, stride=1, seed=19),
     "llama3_w2_stride2": dict(kind="llama3", W=2, cu=[0, 60, 62, 128], H=4, Hk=2, D=32, stride=2, seed=20),
 }
@@ -43,6 +45,13 @@ CASES = {
 def zigzag_extract(x, rank, W, dim):
     ch = x.chunk(2 * W, dim=dim)
     return torch.cat([ch[rank], ch[2 * W - 1 - rank]], dim=dim).contiguous()
+
+
+def stripe_extract(x, rank, W, dim=1):
+    """token t -> rank t mod W   (reference test/test_stripe_flash_attn_func.py:9-14)"""
+    x = torch.stack(x.split(W, dim=dim), dim=dim).transpose(dim, dim + 1)
+    slicer = [rank if i == dim else slice(None) for i in range(len(x.shape))]
+    return x[slicer].contiguous()
 
 
 def varlen_extract(x, cu, rank, W, zigzag):
@@ -82,6 +91,8 @@ def shard(c, rank):
         loc = [zigzag_extract(t, rank, W, 1) for t in (q, k, v, do)]
     elif kind == "ring":
         loc = [t.chunk(W, dim=1)[rank].contiguous() for t in (q, k, v, do)]
+    elif kind == "stripe":
+        loc = [stripe_extract(t, rank, W) for t in (q, k, v, do)]
     elif kind in ("zigzag_varlen", "ring_varlen"):
         zz = kind == "zigzag_varlen"
         loc = [varlen_extract(t, c["cu"], rank, W, zz) for t in (q, k, v, do)]
@@ -103,6 +114,8 @@ def run_case(name, c, rank, ref):
         out, lse, _ = ref["zigzag_ring_flash_attn"].zigzag_ring_flash_attn_func(q, k, v, causal=True, **kw)
     elif kind == "ring":
         out, lse, _ = ref["ring_flash_attn"].ring_flash_attn_func(q, k, v, causal=c["causal"], **kw)
+    elif kind == "stripe":
+        out, lse, _ = ref["stripe_flash_attn"].stripe_flash_attn_func(q, k, v, causal=True, **kw)
     elif kind == "zigzag_varlen":
         out, lse, _ = ref["zigzag_ring_flash_attn_varlen"].zigzag_ring_flash_attn_varlen_func(
             q, k, v, extra["cu_local"], extra["max_local"], causal=True, **kw)

@@ -109,13 +109,13 @@ def test_missing_extension_fails_loudly(monkeypatch, built):
 
 
 def test_public_api_surface():
-    """the 21 public names of reference ring_flash_attn/__init__.py:1-35 minus stripe_* (out of scope)."""
+    """the 21 public names of reference ring_flash_attn/__init__.py:1-35, same signatures."""
     import inspect
     import ring_flash_attn as r
 
     tail = ["dropout_p", "softmax_scale", "causal", "window_size", "alibi_slopes", "deterministic",
             "return_attn_probs", "group"]
-    for prefix, lead in (("ring_flash_attn", []), ("zigzag_ring_flash_attn", []),
+    for prefix, lead in (("ring_flash_attn", []), ("zigzag_ring_flash_attn", []), ("stripe_flash_attn", []),
                          ("ring_flash_attn_varlen", ["cu_seqlens", "max_seqlen"]),
                          ("zigzag_ring_flash_attn_varlen", ["cu_seqlens", "max_seqlen"])):
         for suffix, first in (("func", ["q", "k", "v"]), ("kvpacked_func", ["q", "kv"]), ("qkvpacked_func", ["qkv"])):

@@ -32,3 +32,26 @@ def test_ringcomm_guards(single_rank_group):
     c._reqs = []
     with pytest.raises(RuntimeError, match="commit called twice"):
         c.commit()
+
+
+def test_torch_compile_tolerance(single_rank_group):
+    """the reference runs every test a second time under torch.compile (test/test.sh:23-25); the
+    public callables must survive being wrapped (they are opaque to dynamo and run eagerly)."""
+    import torch
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    try:
+        g = torch.Generator().manual_seed(3)
+        qkv = torch.randn(1, 32, 3, 2, 16, generator=g).to(torch.bfloat16)
+        eager = R.zigzag_ring_flash_attn_qkvpacked_func(qkv, causal=True)
+        torch._dynamo.config.capture_scalar_outputs = True
+        compiled = torch.compile(R.zigzag_ring_flash_attn_qkvpacked_func)
+        x = qkv.clone().requires_grad_(True)
+        out = compiled(x, causal=True)
+        out.sum().backward()
+        assert torch.equal(out, eager) and x.grad is not None and x.grad.shape == qkv.shape
+    finally:
+        backend.set_backend(None)
