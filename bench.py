@@ -20,6 +20,9 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC; RCCL / cross-process device memory need this (see task env)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "ring-flash-attention_amd")):
     if _p not in sys.path:
@@ -211,6 +214,16 @@ def main():
             "traffic": None,
             "avg_launch_ms": t[dom],
         }
+        # HBM bytes per launch come from the committed PMC pass (profiles/r01_traffic.json), not from
+        # this run: counters cannot be collected inside the timed process
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            kn = result["roofline"]["kernel"]
+            if hk == 8 and kn in tr:
+                result["roofline"]["traffic"] = tr[kn]["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t.items()}
         result["kernels_tflops"] = {n: algo[n] / (t[n] * 1e-3) / 1e12 for n in algo}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

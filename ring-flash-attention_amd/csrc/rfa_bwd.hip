@@ -32,6 +32,9 @@
 #ifndef RFA_KV_AHEAD2
 #define RFA_KV_AHEAD2 2      // dkdv: transpose-read fragment pairs ahead in the dV/dK GEMMs
 #endif
+#ifndef RFA_DQ_PIN
+#define RFA_DQ_PIN 0          // >0: pin the dQ transpose-read/MFMA pipeline with this read-ahead depth
+#endif
 #ifndef RFA_DQ_AHEAD1
 #define RFA_DQ_AHEAD1 3
 #endif
@@ -211,6 +214,33 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
+#if RFA_DQ_PIN
+        {
+          const vec8<T> dsb0 = pack8<T>(s, 0), dsb1 = pack8<T>(s, 8);
+          constexpr int kAhead = RFA_DQ_PIN;
+          vec8<T> a[8];
+          auto frag = [&](int i) {                        // i: [ks2][dblk]
+            lds_t* kt = kb + (32 * t + 16 * (i >> 2)) * kRowBytes;
+            vec4<T> lo = lds_read_tr<T>(kt + toff[i & 3][0]);
+            vec4<T> hi = lds_read_tr<T>(kt + toff[i & 3][1]);
+            return concat<T>(lo, hi);
+          };
+#pragma unroll
+          for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i + kAhead < 8) a[i + kAhead] = frag(i + kAhead);
+            dq[i & 3] = mfma(a[i], (i >> 2) ? dsb1 : dsb0, dq[i & 3]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
+#pragma unroll
+          for (int i = 0; i < 8 - kAhead; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
+        }
+#else
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> dsb = pack8<T>(s, 8 * ks2);
@@ -222,6 +252,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
             dq[dblk] = mfma(concat<T>(lo, hi), dsb, dq[dblk]);
           }
         }
+#endif
       }
     }
     if (j + 1 < ntiles) write_tile(buf ^ 1);

@@ -25,6 +25,9 @@
                              // (A/B: 0 -> 0.676 ms, 4 -> 0.648 ms, 8 -> 0.635 ms; accuracy unchanged, see the
                              //  'spike keys' self-test cases that force the rescale branch mid-loop)
 #endif
+#ifndef RFA_FWD_PIN_PV
+#define RFA_FWD_PIN_PV 0     // >0: pin the P.V transpose-read/MFMA pipeline with this read-ahead depth
+#endif
 #ifndef RFA_FWD_AHEAD
 #define RFA_FWD_AHEAD 4
 #endif
@@ -247,6 +250,36 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
       // ---------------- O^T += V^T P^T ----------------
       if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#if RFA_FWD_PIN_PV
+      {
+        // 16 MFMAs (i = [t][ks2][dblk]), each fed by two transpose reads issued kAhead MFMAs ahead
+        vec8<T> pb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pb[u] = pack8<T>(s[u >> 1], 8 * (u & 1));
+        constexpr int kAhead = RFA_FWD_PIN_PV;
+        vec8<T> a[16];
+        auto frag = [&](int i) {
+          lds_t* vb = vtile + (32 * (i >> 3) + 16 * ((i >> 2) & 1)) * kRowBytes;
+          vec4<T> lo = lds_read_tr<T>(vb + voff[i & 3][0]);
+          vec4<T> hi = lds_read_tr<T>(vb + voff[i & 3][1]);
+          return concat<T>(lo, hi);
+        };
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i + kAhead < 16) a[i + kAhead] = frag(i + kAhead);
+          o[i & 3] = mfma(a[i], pb[i >> 2], o[i & 3]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
+#pragma unroll
+        for (int i = 0; i < 16 - kAhead; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
+      }
+#else
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -260,6 +293,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
             o[dblk] = mfma(concat<T>(lo, hi), pb, o[dblk]);
           }
         }
+#endif
       if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
     if (j + 1 < ntiles) write_tile(buf ^ 1);
