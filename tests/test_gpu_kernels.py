@@ -64,6 +64,11 @@ def test_native_selftest_binary(built):
     """torch-free C-ABI self test: layout probes + 20 parity groups against oracle/attn_ref.c"""
     exe = built.build_selftest()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    try:  # keep the full log where gpurun merges it back (post-mortem of any failure)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "selftest_pytest.log"), "w").write(r.stdout + "\n--- stderr ---\n" + r.stderr)
+    except OSError:
+        pass
     print(r.stdout[-3000:])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SELFTEST PASSED" in r.stdout
