@@ -92,3 +92,48 @@ def test_headline_constant_v_and_split_merge(single_rank_group):
     be.fwd(q, k[:, S // 2:], v[:, S // 2:], softmax_scale=scale, causal=False, out_acc=two, lse_acc=l_two)
     assert (l_one - l_two).abs().max().item() < 1e-4
     assert (one - two).abs().max().item() < 2e-3
+
+
+def test_max_length_65536_single_gpu(single_rank_group):
+    """The headline's TOTAL sequence (8192 x 8 = 65536) on one GPU: 64-bit addressing, 256 query blocks
+    per head, 1024 KV tiles.  Size-independent checks: sampled rows of out/lse/dq in fp64 on the host,
+    one key row of dk/dv, and constant-V => constant out."""
+    import ring_flash_attn as R
+
+    dev = torch.device("cuda:0")
+    SL, HH, HKK = 65536, 4, 2
+    g = torch.Generator().manual_seed(65)
+    q = torch.randn(1, SL, HH, D, generator=g).to(torch.bfloat16)
+    kv = torch.randn(1, SL, 2, HKK, D, generator=g).to(torch.bfloat16)
+    do = torch.randn(1, SL, HH, D, generator=g).to(torch.bfloat16)
+    qd, kvd = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+    out, lse, _ = R.zigzag_ring_flash_attn_kvpacked_func(qd, kvd, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    out, lse = out.cpu().double(), lse.cpu().double()
+    dq, dkv = qd.grad.cpu().double(), kvd.grad.cpu().double()
+    qf, kf, vf, dof = q.double(), kv[:, :, 0].double(), kv[:, :, 1].double(), do.double()
+    scale = 1.0 / math.sqrt(D)
+    for i, h in [(0, 0), (255, 1), (256, 2), (32767, 3), (32768, 0), (65535, 1), (50001, 2)]:
+        hk = h // (HH // HKK)
+        s = (kf[0, : i + 1, hk] @ qf[0, i, h]) * scale
+        l = torch.logsumexp(s, 0)
+        p = torch.exp(s - l)
+        o = p @ vf[0, : i + 1, hk]
+        assert abs(l - lse[0, h, i]) < 1e-3
+        assert (o - out[0, i, h]).abs().max() < 1e-2
+        dp = vf[0, : i + 1, hk] @ dof[0, i, h]
+        delta = (dof[0, i, h] * out[0, i, h]).sum()
+        ref_dq = (p * (dp - delta) * scale) @ kf[0, : i + 1, hk]
+        assert (ref_dq - dq[0, i, h]).abs().max() < 5e-3 + 2e-2 * ref_dq.abs().max()
+    j, hk = 60000, 1
+    dk, dv = torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
+    for h in range(hk * (HH // HKK), (hk + 1) * (HH // HKK)):
+        s = (qf[0, j:, h] @ kf[0, j, hk]) * scale
+        p = torch.exp(s - lse[0, h, j:])
+        dp = dof[0, j:, h] @ vf[0, j, hk]
+        delta = (dof[0, j:, h] * out[0, j:, h]).sum(-1)
+        ds = p * (dp - delta) * scale
+        dk += ds @ qf[0, j:, h]
+        dv += p @ dof[0, j:, h]
+    assert (dk - dkv[0, j, 0, hk]).abs().max() < 5e-3 + 2.5e-2 * dk.abs().max()
+    assert (dv - dkv[0, j, 1, hk]).abs().max() < 5e-3 + 2.5e-2 * dv.abs().max()

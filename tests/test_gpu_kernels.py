@@ -214,3 +214,33 @@ def test_smoke_entry(single_rank_group):
     import __graft_entry__ as ge
 
     ge.smoke()
+
+
+def test_varlen_with_empty_sequences(single_rank_group):
+    """packed batch containing zero-length sequences (repeated cu_seqlens entries) and a 1-token one"""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    cu = [0, 0, 70, 70, 71, 300, 300]
+    cut = torch.tensor(cu, dtype=torch.int32)
+    g = torch.Generator().manual_seed(46)
+    q = torch.randn(300, 4, 128, generator=g).to(BF)
+    k = torch.randn(300, 2, 128, generator=g).to(BF)
+    v = torch.randn(300, 2, 128, generator=g).to(BF)
+    do = torch.randn(300, 4, 128, generator=g).to(BF)
+    qd, kd, vd = [t.to(dev).requires_grad_(True) for t in (q, k, v)]
+    out, lse, _ = R.ring_flash_attn_varlen_func(qd, kd, vd, cut.to(dev), 229, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    ro, rl, dq, dk, dv = _oracle_varlen(q, k, v, do, cut, cut, True)
+    _check("out", out, ro, 2e-2)
+    _check("lse", lse, rl, 1e-3)
+    _grads_ok("empty-seqs", (qd.grad, kd.grad, vd.grad), (dq, dk, dv))
+
+
+def test_empty_problem_is_noop(single_rank_group):
+    import ring_flash_attn as R
+
+    dev = _dev()
+    q = torch.empty(1, 0, 4, 128, device=dev, dtype=BF)
+    out, lse, _ = R.ring_flash_attn_func(q, q, q, causal=True, return_attn_probs=True)
+    assert out.shape == (1, 0, 4, 128) and lse.shape == (1, 4, 0)
