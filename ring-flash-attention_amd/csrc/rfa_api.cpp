@@ -67,9 +67,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   if (a->out_acc) {
     if (!aligned16(a->out_acc) || !stride_ok(a->out_acc_st, 4)) return RFA_ERR_ALIGN;
   } else {
-    if ((reinterpret_cast<uintptr_t>(a->out) & 7) || (a->out_st.row % 4) || (a->out_st.head % 4) ||
-        (a->out_st.batch % 4))
-      return RFA_ERR_ALIGN;
+    if (!aligned16(a->out) || !stride_ok(a->out_st, 2)) return RFA_ERR_ALIGN;
   }
   FwdParams p{};
   p.q = a->q; p.k = a->k; p.v = a->v;
@@ -133,6 +131,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   if (!stride_ok(a->dout_st, 2) || !stride_ok(a->q_st, 2) || !stride_ok(a->k_st, 2) || !stride_ok(a->v_st, 2))
     return RFA_ERR_ALIGN;
   if (a->dq_acc && (!aligned16(a->dq_acc) || !stride_ok(a->dq_acc_st, 4))) return RFA_ERR_ALIGN;
+  if (!a->dq_acc && (!aligned16(a->dq) || !stride_ok(a->dq_st, 2))) return RFA_ERR_ALIGN;
   if (a->dk_acc && (!aligned16(a->dk_acc) || !aligned16(a->dv_acc) || !stride_ok(a->dk_acc_st, 4) ||
                     !stride_ok(a->dv_acc_st, 4)))
     return RFA_ERR_ALIGN;

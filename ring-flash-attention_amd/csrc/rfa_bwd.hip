@@ -263,18 +263,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   const int64_t orow = qs.row0 + qrow;
   if (p.dq_acc == nullptr) {
     T* ob = (T*)p.dq + qbatch * p.dq_st.batch + orow * p.dq_st.row + (int64_t)h * p.dq_st.head;
-#pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (kFullD || d0 < p.D) {
-          f32x4 x;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = dq[dblk][4 * jj + e] * p.scale;
-          *(vec4<T>*)(ob + d0) = __builtin_convertvector(x, vec4<T>);
-        }
-      }
+    store_rows16<T, kFullD>(ob, dq, p.scale, g, p.D, true);
   } else {
     float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + orow * p.dq_acc_st.row +
                 (int64_t)h * p.dq_acc_st.head;
@@ -622,22 +611,8 @@ __global__ __launch_bounds__(kKvThreads) void dkdv_kernel(const BwdParams p) {
   const int64_t orow = ks.row0 + krow;
   T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)h * p.dk_st.head;
   T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)h * p.dv_st.head;
-#pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int d0 = 32 * dblk + 8 * jj + 4 * g;
-      if (kFullD || d0 < p.D) {
-        f32x4 x, y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          x[e] = dk[dblk][4 * jj + e] * p.scale;
-          y[e] = dv[dblk][4 * jj + e];
-        }
-        *(vec4<T>*)(dkb + d0) = __builtin_convertvector(x, vec4<T>);
-        *(vec4<T>*)(dvb + d0) = __builtin_convertvector(y, vec4<T>);
-      }
-    }
+  store_rows16<T, kFullD>(dkb, dk, p.scale, g, p.D, true);
+  store_rows16<T, kFullD>(dvb, dv, 1.f, g, p.D, true);
 }
 
 // =====================================================================================
@@ -915,18 +890,7 @@ __global__ __launch_bounds__(kKv2Threads, 2) void dkdv2_kernel(const BwdParams p
   T* ob = role == 0 ? (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)h * p.dv_st.head
                     : (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)h * p.dk_st.head;
   const float oscale = role == 0 ? 1.f : p.scale;
-#pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int d0 = 32 * dblk + 8 * jj + 4 * g;
-      if (kFullD || d0 < p.D) {
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = acc[dblk][4 * jj + e] * oscale;
-        *(vec4<T>*)(ob + d0) = __builtin_convertvector(y, vec4<T>);
-      }
-    }
+  store_rows16<T, kFullD>(ob, acc, oscale, g, p.D, true);
 }
 
 template <typename T, bool kFullD>

@@ -149,6 +149,36 @@ __device__ __forceinline__ SeqSpan resolve_span(const int32_t* cu, int b, int S,
 // otherwise hipcc's in-loop waits for it also drain the loop's own prefetch loads.
 __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+// Epilogue store of a wave's C-layout tile as 16-bit rows.  acc[dblk][4*jj + e] of lane (row = l&31,
+// g = l>>5) is column 32*dblk + 8*jj + 4*g + e: the two half-waves of a row each hold 4 of every 8
+// consecutive columns.  One v_permlane32_swap per dword exchanges "upper half's group jj" with "lower
+// half's group jj+1", after which each lane owns 8 consecutive columns = ONE 16-byte store (lower
+// half: group jj, upper half: group jj+1) instead of two 8-byte stores.  All 64 lanes must call it.
+template <typename T, bool kFullD>
+__device__ __forceinline__ void store_rows16(T* row_ptr, const f32x16 (&acc)[4], float scale, int g, int D,
+                                             bool row_ok) {
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x4 x0, x1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x0[e] = acc[dblk][8 * m + e] * scale;         // group jj = 2m
+        x1[e] = acc[dblk][8 * m + 4 + e] * scale;     // group jj = 2m + 1
+      }
+      const vec4<T> h0 = __builtin_convertvector(x0, vec4<T>);
+      const vec4<T> h1 = __builtin_convertvector(x1, vec4<T>);
+      i32x2 a = __builtin_bit_cast(i32x2, h0), b = __builtin_bit_cast(i32x2, h1);
+      auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+      auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+      i32x4 w;
+      w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];
+      const int d0 = 32 * dblk + 16 * m + 8 * g;
+      if (row_ok && (kFullD || d0 < D)) *(i32x4*)(row_ptr + d0) = w;
+    }
+}
+
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -310,18 +310,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
   if (p.out_acc == nullptr) {
     T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
-#pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (kFullD || d0 < p.D) {
-          f32x4 x;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
-          *(vec4<T>*)(ob + d0) = __builtin_convertvector(x, vec4<T>);
-        }
-      }
+    store_rows16<T, kFullD>(ob, o, inv, g, p.D, true);
     if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
   } else {
     float* ab = p.out_acc + qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row +
