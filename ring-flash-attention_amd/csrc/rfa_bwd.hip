@@ -24,9 +24,6 @@
 #include "rfa_kernels.hpp"
 
 // ---- tuning knobs (A/B'd on hardware with tools/ab_variants.py; defaults = best measured) ----
-#ifndef RFA_DQ_PIN
-#define RFA_DQ_PIN 0          // >0: pin the dQ transpose-read/MFMA pipeline with this read-ahead depth
-#endif
 #ifndef RFA_DQ_AHEAD1
 #define RFA_DQ_AHEAD1 3
 #endif
@@ -113,41 +110,77 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   const int sc = tid & 15;
   const int sr = tid >> 4;
   const bool sd_ok = kFullD || sc * 8 < p.D;
+  // K/V tiles are fetched with raw buffer loads (fixed per-thread byte offsets, the tile advance lives in
+  // the scalar descriptor, rows past the end of the sequence read as zero).  With D == 128 they go
+  // global -> LDS directly (buffer_load ... lds): a wave-instruction fills 64 consecutive 16-byte slots =
+  // 4 tile rows, so lane L of the DMA for row group c = wave + 8 i lands in row 4c + L/16, physical
+  // chunk L%16 and must FETCH the logical chunk the swizzle puts there.  D < 128 needs the chunks
+  // beyond D zeroed and takes the register path.
+  constexpr bool kDma = kFullD;
   vec8<T> kreg[2], vreg[2];
-  auto load_tile = [&](int j) {
+  int voff_k[2], voff_v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = sr + 32 * i, chunk = sc;
+    if (kDma) {
+      row = 4 * (wave + 8 * i) + (lane >> 4);
+      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
+    }
+    voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
+    voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
+  }
+  auto load_tile = [&](int j, auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    int rows = lk - j * kDqKV;
+    rows = rows < kDqKV ? rows : kDqKV;
+    const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
+    const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
+    const buf_rsrc_t rk = make_rsrc(kbase + (int64_t)j * kDqKV * p.k_st.row, nk);
+    const buf_rsrc_t rv = make_rsrc(vbase + (int64_t)j * kDqKV * p.v_st.row, nv);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int kr = j * kDqKV + sr + 32 * i;
-      kr = kr < lk ? kr : lk - 1;
-      kr = kr < 0 ? 0 : kr;
-      if (sd_ok) {
-        kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
-        vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
+      if (kDma) {
+        lds_t* dst = smem + kStage * kDqTileBytes + (wave + 8 * i) * 1024;
+        buffer_load128_lds(rk, dst, voff_k[i]);
+        buffer_load128_lds(rv, dst + 2 * kDqTileBytes, voff_v[i]);
       } else {
-        kreg[i] = zero8<T>();
-        vreg[i] = zero8<T>();
+        kreg[i] = buffer_load128<T>(rk, voff_k[i]);
+        vreg[i] = buffer_load128<T>(rv, voff_v[i]);
+        if (!sd_ok) {
+          kreg[i] = zero8<T>();
+          vreg[i] = zero8<T>();
+        }
       }
     }
   };
-  auto write_tile = [&](int buf) {
+  auto write_tile = [&](auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    if (!kDma) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int o = tile_off(sr + 32 * i, sc);
-      lds_write128<T>(smem + buf * kDqTileBytes + o, kreg[i]);
-      lds_write128<T>(smem + (2 + buf) * kDqTileBytes + o, vreg[i]);
+      for (int i = 0; i < 2; ++i) {
+        const int o = tile_off(sr + 32 * i, sc);
+        lds_write128<T>(smem + kStage * kDqTileBytes + o, kreg[i]);
+        lds_write128<T>(smem + (2 + kStage) * kDqTileBytes + o, vreg[i]);
+      }
     }
   };
 
   int koff[8];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) koff[kk] = tile_off(l31, 2 * kk + g);
+  for (int kk = 0; kk < 8; ++kk) {
+    koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);
+    pin_vgpr(koff[kk]);
+  }
   int toff[4][2];
 #pragma unroll
   for (int dblk = 0; dblk < 4; ++dblk)
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
-      toff[dblk][hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
+    {
+      toff[dblk][hh] = lds_addr(smem) + (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
                        tr_lane_off(lane, dblk, (2 * hh + g) & 3);
+      pin_vgpr(toff[dblk][hh]);
+    }
 
   const float c = p.scale * kLog2e;
   f32x16 dq[4];
@@ -156,16 +189,21 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
-  load_tile(0);            // unconditional (rows clamped): one path into the loop, see rfa_fwd.hip
-  write_tile(0);
+  typedef std::integral_constant<int, 0> stage0_t;
+  typedef std::integral_constant<int, 1> stage1_t;
+  load_tile(0, stage0_t{});   // unconditional (rows past the end read as zero): one path into the loop
+  write_tile(stage0_t{});
   wait_all_vmem();
   __syncthreads();
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int buf = j & 1;
-    lds_t* kb = smem + buf * kDqTileBytes;
-    lds_t* vb = smem + (2 + buf) * kDqTileBytes;
-    if (j + 1 < ntiles) load_tile(j + 1);
+  // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by two), so every
+  // LDS address in here is a per-lane table entry plus an instruction immediate: no address arithmetic.
+  auto tile_step = [&](int j, auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    constexpr int kbo = kStage * kDqTileBytes;            // K stage
+    constexpr int vbo = (2 + kStage) * kDqTileBytes;      // V stage
+    typedef std::integral_constant<int, kStage ^ 1> next_t;
+    if (j + 1 < ntiles) load_tile(j + 1, next_t{});
     const int kt0 = j * kDqKV;
     const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
     if (active) {
@@ -180,13 +218,14 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
           // S^T = K Q^T and dP^T = V dO^T as one 16-step pipeline, A fragments read kAhead ahead
           constexpr int kAhead = RFA_DQ_AHEAD1;
           vec8<T> a[16];
+          auto fa = [&](int i) {
+            return lds_read128<T>(lds_ptr(koff[i & 7]) + (i < 8 ? kbo : vbo) + t * 32 * kRowBytes);
+          };
 #pragma unroll
-          for (int i = 0; i < kAhead; ++i)
-            a[i] = lds_read128<T>((i < 8 ? kb : vb) + t * 32 * kRowBytes + koff[i & 7]);
+          for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            if (i + kAhead < 16)
-              a[i + kAhead] = lds_read128<T>(((i + kAhead) < 8 ? kb : vb) + t * 32 * kRowBytes + koff[(i + kAhead) & 7]);
+            if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
             if (i < 8) s = mfma(a[i], qf[i], s);
             else dp = mfma(a[i], dof[i - 8], dp);
           }
@@ -209,49 +248,26 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
-#if RFA_DQ_PIN
-        {
-          const vec8<T> dsb0 = pack8<T>(s, 0), dsb1 = pack8<T>(s, 8);
-          constexpr int kAhead = RFA_DQ_PIN;
-          vec8<T> a[8];
-          auto frag = [&](int i) {                        // i: [ks2][dblk]
-            lds_t* kt = kb + (32 * t + 16 * (i >> 2)) * kRowBytes;
-            vec4<T> lo = lds_read_tr<T>(kt + toff[i & 3][0]);
-            vec4<T> hi = lds_read_tr<T>(kt + toff[i & 3][1]);
-            return concat<T>(lo, hi);
-          };
-#pragma unroll
-          for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            if (i + kAhead < 8) a[i + kAhead] = frag(i + kAhead);
-            dq[i & 3] = mfma(a[i], (i >> 2) ? dsb1 : dsb0, dq[i & 3]);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
-#pragma unroll
-          for (int i = 0; i < 8 - kAhead; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-          }
-          __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
-        }
-#else
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> dsb = pack8<T>(s, 8 * ks2);
-          lds_t* kt = kb + (32 * t + 16 * ks2) * kRowBytes;
 #pragma unroll
           for (int dblk = 0; dblk < 4; ++dblk) {
-            vec4<T> lo = lds_read_tr<T>(kt + toff[dblk][0]);
-            vec4<T> hi = lds_read_tr<T>(kt + toff[dblk][1]);
+            const int imm = kbo + (32 * t + 16 * ks2) * kRowBytes;
+            vec4<T> lo = lds_read_tr<T>(lds_ptr(toff[dblk][0]) + imm);
+            vec4<T> hi = lds_read_tr<T>(lds_ptr(toff[dblk][1]) + imm);
             dq[dblk] = mfma(concat<T>(lo, hi), dsb, dq[dblk]);
           }
         }
-#endif
       }
     }
-    if (j + 1 < ntiles) write_tile(buf ^ 1);
+    if (j + 1 < ntiles) write_tile(next_t{});
+    if (kDma) wait_all_vmem();                           // the DMA of tile j+1 must have landed before the barrier
     __syncthreads();
+  };
+  for (int j = 0; j < ntiles; j += 2) {
+    tile_step(j, stage0_t{});
+    if (j + 1 < ntiles) tile_step(j + 1, stage1_t{});
   }
 
   if (qrow >= lq) return;
@@ -309,11 +325,15 @@ template <typename T, bool kFullD>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
-  lds_t* ktile = smem;                                // [128 keys][128] swizzled
-  lds_t* vtile = smem + kKvKvBytes;
-  lds_t* qd = smem + 2 * kKvKvBytes;                 // Q[2] then dO[2], 16 KiB each
-  lds_t* stat_base = qd + 4 * kKvTileBytes;
+  // LDS map (bytes): Q[2] 0 / 16K, dO[2] 32K / 48K, V 64K, stats[2] 128K.  Every address used in
+  // the main loop is ONE per-lane VGPR (toggled between the two stages with an XOR once per tile) plus a
+  // compile-time immediate — no vector address arithmetic beside the swizzle XORs.
+  constexpr int kOffDo = 2 * kKvTileBytes;            // dO = Q + 32K  (immediate)
+  constexpr int kOffV = 4 * kKvTileBytes;             // 64K
+  constexpr int kOffStat = kOffV + 2 * kKvKvBytes;    // 128K (96K..128K is only used by the final exchange)
+  lds_t* vtile = smem + kOffV;                        // [128 keys][128] swizzled
 
+  if (lds_addr(smem) & 0xffff) __builtin_trap();     // address XOR tricks below need a 64 KiB-aligned block
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -363,66 +383,111 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int sr = tid >> 4;                    // 0..31
   const bool sd_ok = kFullD || sc * 8 < p.D;
 
-  // ---- stage the workgroup's K / V rows once: 128 rows x 16 chunks x 2 tensors = 8 chunks / thread
+  // ---- V rows of the workgroup go to LDS once (128 rows x 16 chunks = 4 chunks / thread); this wave's
+  // K rows stay in registers as the B operand of the S GEMM (32 registers)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = sr + 32 * i;
     int kr = kwg0 + row;
     kr = kr < lk ? kr : lk - 1;
-    vec8<T> kc = zero8<T>(), vc = zero8<T>();
-    if (sd_ok) {
-      kc = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
-      vc = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
-    }
-    lds_write128<T>(ktile + tile_off(row, sc), kc);
+    vec8<T> vc = zero8<T>();
+    if (sd_ok) vc = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
     lds_write128<T>(vtile + tile_off(row, sc), vc);
+  }
+  vec8<T> kwr[8];
+  {
+    const int kr = krow < lk ? krow : lk - 1;
+    const T* kp = kbase + (int64_t)kr * p.k_st.row;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int chunk = 2 * kk + g;
+      kwr[kk] = (kFullD || chunk * 8 < p.D) ? *(const vec8<T>*)(kp + chunk * 8) : zero8<T>();
+    }
   }
 
   vec8<T> qreg[2], doreg[2];
   float statreg = 0.f;
+  // Row statistics are stored pre-multiplied (one multiply per staged value, done at LDS-write time when
+  // the load has long landed): lse by -log2(e), so that P = exp2(S*c + stat) is a single FMA per element,
+  // and delta by -1, so that it can be loaded straight into the dP accumulator (dP - delta for free).
+  const float stat_scale = (tid & kKvQ) ? -1.f : -kLog2e;
+  // Q/dO tiles are fetched with raw buffer loads: the per-thread byte offsets are fixed for the whole
+  // kernel and the tile advance lives in the (scalar) buffer descriptor, so a tile costs no vector
+  // address arithmetic; rows past the end of the sequence are out of the descriptor's range and read
+  // as zero (no clamping).  The descriptor covers exactly the tile's valid rows of this head.
+  // With D == 128 the tile goes global -> LDS directly (buffer_load ... lds, no staging registers): a
+  // wave-instruction fills 64 consecutive 16-byte slots = 4 tile rows, so lane L of the DMA for row
+  // group c = wave + 8 i lands in row 4c + L/16, physical chunk L%16 and must FETCH the logical chunk
+  // that the swizzle puts there.  Otherwise (D < 128) the chunks beyond D have to be zeroed, which
+  // needs the register path.
+  constexpr bool kDma = kFullD;
+  int voff_q[2], voff_do[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = sr + 32 * i, chunk = sc;
+    if (kDma) {
+      row = 4 * (wave + 8 * i) + (lane >> 4);
+      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
+    }
+    voff_q[i] = (row * (int)p.q_st.row + chunk * 8) * 2;
+    voff_do[i] = (row * (int)p.dout_st.row + chunk * 8) * 2;
+  }
+  int dma_stage = 0;                                  // LDS stage the next load_tile() fills (scalar)
   auto load_tile = [&](int j) {
+    int rows = lq - j * kKvQ;
+    rows = rows < kKvQ ? rows : kKvQ;
+    const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
+    const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
+    const buf_rsrc_t rq = make_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
+    const buf_rsrc_t rdo = make_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int qr = j * kKvQ + sr + 32 * i;
-      qr = qr < lq ? qr : lq - 1;
-      qr = qr < 0 ? 0 : qr;
-      if (sd_ok) {
-        qreg[i] = *(const vec8<T>*)(qbase + (int64_t)qr * p.q_st.row + sc * 8);
-        doreg[i] = *(const vec8<T>*)(dobase + (int64_t)qr * p.dout_st.row + sc * 8);
+      if (kDma) {
+        lds_t* dst = smem + dma_stage + (wave + 8 * i) * 1024;
+        buffer_load128_lds(rq, dst, voff_q[i]);
+        buffer_load128_lds(rdo, dst + kOffDo, voff_do[i]);
       } else {
-        qreg[i] = zero8<T>();
-        doreg[i] = zero8<T>();
+        qreg[i] = buffer_load128<T>(rq, voff_q[i]);
+        doreg[i] = buffer_load128<T>(rdo, voff_do[i]);
+        if (!sd_ok) {                          // chunk beyond D but inside the row: not covered by the range check
+          qreg[i] = zero8<T>();
+          doreg[i] = zero8<T>();
+        }
       }
     }
-    {
-      int qr = j * kKvQ + (tid & (kKvQ - 1));
-      qr = qr < lq ? qr : lq - 1;
-      qr = qr < 0 ? 0 : qr;
-      const float* sp = (tid & kKvQ) ? dltbase : lsebase;
-      statreg = sp[qr];                        // raw value: any arithmetic here would wait on the load and drain the prefetch
+    if (wave < 2) {                            // wave 0 stages lse, wave 1 delta (wave-uniform descriptor)
+      const buf_rsrc_t rs = make_rsrc((wave ? dltbase : lsebase) + j * kKvQ, rows > 0 ? rows * 4 : 0);
+      statreg = buffer_load32(rs, lane * 4);   // raw value: arithmetic here would wait on the load and drain the prefetch
     }
+    dma_stage ^= kKvTileBytes;
   };
-  auto write_tile = [&](int buf) {
+  int wq = lds_addr(smem) + tile_off(sr, sc);                          // staging write address, stage 0 (row + 32: +8K immediate)
+  int ws = lds_addr(smem) + kOffStat + tid * 4;
+  auto write_tile = [&]() {
+    if (!kDma) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int o = tile_off(sr + 32 * i, sc);
-      lds_write128<T>(qd + buf * kKvTileBytes + o, qreg[i]);
-      lds_write128<T>(qd + (2 + buf) * kKvTileBytes + o, doreg[i]);
+      for (int i = 0; i < 2; ++i) {
+        lds_write128<T>(lds_ptr(wq) + i * 32 * kRowBytes, qreg[i]);
+        lds_write128<T>(lds_ptr(wq) + i * 32 * kRowBytes + kOffDo, doreg[i]);
+      }
     }
-    if (tid < 2 * kKvQ)
-      *(__attribute__((address_space(3))) float*)(stat_base + buf * kKvStatBytes + tid * 4) = statreg;
+    if (tid < 2 * kKvQ) *(__attribute__((address_space(3))) float*)lds_ptr(ws) = statreg * stat_scale;
   };
 
-  // Fragment offsets are kept as ONE base each and derived with an XOR at the point of use (the swizzle
-  // makes chunk selection an XOR on address bits 4..7): 16 fewer live registers than offset tables,
-  // which is what lets this kernel fit the 256-register budget of two waves per SIMD.
-  int aoff0 = tile_off(l31, g);                       // aoff(kk) = aoff0 ^ (kk << 5)
-  int toff0[2];                                        // toff(dblk, hh) = toff0[hh] ^ (dblk << 6)
+  // Fragment addresses: the swizzle makes chunk selection an XOR on address bits 4..7, so a fragment's
+  // address is (one base register) ^ (kk << 5) resp. ^ (dblk << 6) — far fewer live registers than
+  // offset tables, which is what lets this kernel fit the 256-register budget of two waves per SIMD.
+  // (XOR toggling / swizzling on absolute addresses: the dynamic LDS block starts 64 KiB-aligned — at 0 —
+  //  because these kernels have no static LDS; checked at the top of the kernel)
+  int aq = lds_addr(smem) + tile_off(l31, g) + par * 32 * kRowBytes;                 // Q / dO sub-tile rows (stage toggled)
+  const int av = lds_addr(smem) + tile_off(l31, g) + kOffV + kbw * 32 * kRowBytes;   // this wave's V rows
+  int tq[2];                                                        // transpose-read bases (stage toggled)
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh)
-    toff0[hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes + tr_lane_off(lane, 0, (2 * hh + g) & 3);
-  lds_t* kw = ktile + kbw * 32 * kRowBytes;          // this wave's 32 key rows (same lane map as aoff)
-  lds_t* vw = vtile + kbw * 32 * kRowBytes;
+    tq[hh] = lds_addr(smem) + (32 * par + 8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes + tr_lane_off(lane, 0, (2 * hh + g) & 3);
+  int sa = lds_addr(smem) + kOffStat + (32 * par + 4 * g) * 4;                       // row statistics (stage toggled)
+  int avp = av;
+  pin_vgpr(aq); pin_vgpr(avp); pin_vgpr(tq[0]); pin_vgpr(tq[1]); pin_vgpr(sa); pin_vgpr(wq); pin_vgpr(ws);
 
   const float c = p.scale * kLog2e;
   f32x16 dk[4], dv[4];
@@ -432,7 +497,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
   load_tile(jt0);
-  write_tile(0);
+  write_tile();
+  wq ^= kKvTileBytes;
+  ws ^= kKvStatBytes;
   wait_all_vmem();
   __syncthreads();
 
@@ -441,56 +508,58 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   if (par == 0) __builtin_amdgcn_s_setprio(2);
 #endif
   for (int j = jt0; j < jt1; ++j) {
-    const int buf = (j - jt0) & 1;
-    asm volatile("" : "+v"(aoff0), "+v"(toff0[0]), "+v"(toff0[1]));   // keep the XORs inside the loop
-    lds_t* qb = qd + buf * kKvTileBytes;
-    lds_t* dob = qd + (2 + buf) * kKvTileBytes;
-    lds_t* st = stat_base + buf * kKvStatBytes;
     if (j + 1 < jt1) load_tile(j + 1);
     const int qs0 = j * kKvQ + 32 * t;
     const bool active = (kw0 < lk) && (qs0 < lq) && !(p.causal && qs0 + 31 + off < kw0);
     if (active) {
       f32x16 s, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]: 4 LDS reads, no VALU
+        const f32x4 nd = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kKvQ + 8 * jj) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = nd[e]; s[4 * jj + e] = 0.f; }
+      }
       {
-        // S = Q K_w^T then dP = dO V_w^T: 16 MFMAs, BOTH operands from LDS, read kAhead steps ahead
+        // dP - delta = dO V_w^T (+ init; V_w fragments from LDS) then S = Q K_w^T (K_w in registers):
+        // 16 MFMAs, LDS operands read kAhead steps ahead
         constexpr int kAhead = RFA_KV_AHEAD;
-        vec8<T> a[16], w[16];
-        auto fa = [&](int i) { return lds_read128<T>((i < 8 ? qb : dob) + t * 32 * kRowBytes + (aoff0 ^ ((i & 7) << 5))); };
-        auto fw = [&](int i) { return lds_read128<T>((i < 8 ? kw : vw) + (aoff0 ^ ((i & 7) << 5))); };
+        vec8<T> a[16], w[8];
+        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + (i < 8 ? kOffDo : 0)); };
+        auto fw = [&](int i) { return lds_read128<T>(lds_ptr(avp ^ (i << 5))); };
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) { a[i] = fa(i); w[i] = fw(i); }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16) { a[i + kAhead] = fa(i + kAhead); w[i + kAhead] = fw(i + kAhead); }
-          if (i < 8) s = mfma(a[i], w[i], s);
-          else dp = mfma(a[i], w[i], dp);
+          if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
+          if (i + kAhead < 8) w[i + kAhead] = fw(i + kAhead);
+          if (i < 8) dp = mfma(a[i], w[i], dp);
+          else s = mfma(a[i], kwr[i - 8], s);
         }
 #if RFA_KV_PIN
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * kAhead, 0);
 #pragma unroll
-        for (int i = 0; i < 16 - kAhead; ++i) {
+        for (int i = 0; i < 8 - kAhead; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
 #endif
       }
-      // row statistics are read only now: holding them across GEMM 1 would cost 32 registers
-      f32x4 l2v[4], dlv[4];
+      // lse is read only now: holding it across GEMM 1 would cost 16 registers
+      f32x4 l2v[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int rq = 32 * t + 8 * jj + 4 * g;
-        l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(st + rq * 4);
-        dlv[jj] = *(__attribute__((address_space(3))) f32x4*)(st + (kKvQ + rq) * 4);
-      }
+      for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
       const bool need_mask = (qs0 + 32 > lq) || (p.causal && qs0 + off < kw0 + 31);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * l2v[jj][e]));
+          s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, l2v[jj][e]));
       if (need_mask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -502,7 +571,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dp[4 * jj + e] = s[4 * jj + e] * (dp[4 * jj + e] - dlv[jj][e]);
+        for (int e = 0; e < 4; ++e) dp[4 * jj + e] *= s[4 * jj + e];
       {
         const vec8<T> pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 8);
         const vec8<T> ds0 = pack8<T>(dp, 0), ds1 = pack8<T>(dp, 8);
@@ -510,9 +579,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         vec8<T> a[16];
         auto frag = [&](int i) {                       // i: [ks2][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk]
           const int ks2 = i >> 3, which = (i >> 2) & 1, dblk = i & 3;
-          lds_t* base = (which ? qb : dob) + (32 * t + 16 * ks2) * kRowBytes;
-          vec4<T> lo = lds_read_tr<T>(base + (toff0[0] ^ (dblk << 6)));
-          vec4<T> hi = lds_read_tr<T>(base + (toff0[1] ^ (dblk << 6)));
+          const int imm = (which ? 0 : kOffDo) + 16 * ks2 * kRowBytes;
+          vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[0] ^ (dblk << 6)) + imm);
+          vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[1] ^ (dblk << 6)) + imm);
           return concat<T>(lo, hi);
         };
 #pragma unroll
@@ -535,7 +604,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #endif
       }
     }
-    if (j + 1 < jt1) write_tile(buf ^ 1);
+    if (j + 1 < jt1) write_tile();
+    aq ^= kKvTileBytes;                                // flip every stage-dependent address
+    tq[0] ^= kKvTileBytes;
+    tq[1] ^= kKvTileBytes;
+    sa ^= kKvStatBytes;
+    wq ^= kKvTileBytes;
+    ws ^= kKvStatBytes;
+    if (kDma) wait_all_vmem();                         // the DMA of tile j+1 must have landed before the barrier
     __syncthreads();
   }
 

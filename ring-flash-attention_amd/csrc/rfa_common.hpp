@@ -55,6 +55,15 @@ __device__ __forceinline__ int tile_off(int row, int chunk) {
   return row * kRowBytes + ((chunk ^ swz(row)) << 4);
 }
 
+// Absolute LDS addresses as plain 32-bit integers: per-lane bases are computed ONCE (dynamic-LDS base
+// included) and the hot loops only add instruction immediates / XOR swizzle bits, instead of re-adding
+// the (link-time) base symbol at every access.
+__device__ __forceinline__ int lds_addr(lds_t* p) { return (int)(unsigned)(__UINTPTR_TYPE__)p; }
+// keeps the compiler from splitting a finished per-lane address back into (base symbol) + (offset) and
+// re-adding the two inside the loop
+__device__ __forceinline__ void pin_vgpr(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ lds_t* lds_ptr(int addr) { return (lds_t*)(__UINTPTR_TYPE__)(unsigned)addr; }
+
 template <typename T>
 __device__ __forceinline__ vec8<T> lds_read128(lds_t* p) {
   return *(__attribute__((address_space(3))) vec8<T>*)p;
@@ -177,6 +186,24 @@ __device__ __forceinline__ void store_rows16(T* row_ptr, const f32x16 (&acc)[4],
       const int d0 = 32 * dblk + 16 * m + 8 * g;
       if (row_ok && (kFullD || d0 < D)) *(i32x4*)(row_ptr + d0) = w;
     }
+}
+
+// Raw buffer access (MUBUF): a 128-bit descriptor in SGPRs {base, num_records bytes, flags}, a 32-bit
+// per-lane byte offset; lanes whose offset falls outside num_records read 0.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const void* base, int num_bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_bytes, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ vec8<T> buffer_load128(buf_rsrc_t r, int voffset) {
+  return __builtin_bit_cast(vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 0));
+}
+// global -> LDS without staging registers: lane L's 16 bytes land at lds_wave_base + 16 L
+__device__ __forceinline__ void buffer_load128_lds(buf_rsrc_t r, lds_t* lds_wave_base, int voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ float buffer_load32(buf_rsrc_t r, int voffset) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 0));
 }
 
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
