@@ -7,26 +7,22 @@
 //
 // Structure (one workgroup = 8 waves = 256 query rows of one head; KV tile = 64 keys):
 //   * each wave owns 32 query rows; its Q fragment lives in registers for the whole kernel
-//   * K/V tiles are staged global -> registers -> LDS (issue early / write late), double
+//   * K/V tiles go global -> LDS by DMA (buffer_load ... lds; D < 128: through registers), double
 //     buffered, one barrier per tile; LDS images are XOR-swizzled (rfa_common.hpp)
 //   * S^T = K·Q^T   (A = K rows from LDS via ds_read_b128, B = Q registers): a lane owns ONE
 //     query row (column of S^T) -> row max / row sum are in-lane, one cross-half exchange
 //   * O^T += V^T·P^T (A = V^T via ds_read_b64_tr_b16, B = P straight from the S^T registers)
 //   * epilogue: normalise, write out/lse, or merge into (out_acc, lse_acc) in fp32.
+#include <type_traits>
+
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
 
 // ---- tuning knobs (A/B'd on hardware with tools/ab_variants.py; defaults = best measured) ----
-#ifndef RFA_FWD_PRIO
-#define RFA_FWD_PRIO 0       // 1: s_setprio(1) around MFMA clusters; 2: static priority for waves 4-7
-#endif
 #ifndef RFA_FWD_DEFER
 #define RFA_FWD_DEFER 8      // >0: skip the O/l rescale while the row max grew by <= this many log2 units
                              // (A/B: 0 -> 0.676 ms, 4 -> 0.648 ms, 8 -> 0.635 ms; accuracy unchanged, see the
                              //  'spike keys' self-test cases that force the rescale branch mid-loop)
-#endif
-#ifndef RFA_FWD_PIN_PV
-#define RFA_FWD_PIN_PV 0     // >0: pin the P.V transpose-read/MFMA pipeline with this read-ahead depth
 #endif
 #ifndef RFA_FWD_AHEAD
 #define RFA_FWD_AHEAD 4
@@ -98,50 +94,83 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   if (p.causal && qend + off < kmax) kmax = qend + off;
   const int ntiles = kmax > 0 ? (kmax + kFwdKV - 1) / kFwdKV : 0;
 
-  // ---- staging assignment: thread -> chunk c of rows r0, r0+32
+  // ---- K/V tile staging.  Raw buffer loads: the per-thread byte offsets are fixed for the whole kernel,
+  // the tile advance lives in the scalar descriptor, rows past the end of the sequence read as zero.
+  // With D == 128 the tile goes global -> LDS directly (buffer_load ... lds, no staging registers and no
+  // LDS-write instructions): a wave-instruction fills 64 consecutive 16-byte slots = 4 tile rows, so lane
+  // L of the DMA for row group c = wave + 8 i lands in row 4c + L/16, physical chunk L%16 and must FETCH
+  // the logical chunk the swizzle puts there.  D < 128 needs the chunks beyond D zeroed and goes
+  // global -> registers -> LDS (issue early / write late).
+  constexpr bool kDma = kFullD;
   const int sc = tid & 15;
   const int sr = tid >> 4;
   const bool sd_ok = kFullD || sc * 8 < p.D;
   vec8<T> kreg[2], vreg[2];
-
-  auto load_tile = [&](int j) {
+  int voff_k[2], voff_v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = sr + 32 * i, chunk = sc;
+    if (kDma) {
+      row = 4 * (wave + 8 * i) + (lane >> 4);
+      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
+    }
+    voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
+    voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
+  }
+  auto load_tile = [&](int j, auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    int rows = lk - j * kFwdKV;
+    rows = rows < kFwdKV ? rows : kFwdKV;
+    const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
+    const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
+    const buf_rsrc_t rk = make_rsrc(kbase + (int64_t)j * kFwdKV * p.k_st.row, nk);
+    const buf_rsrc_t rv = make_rsrc(vbase + (int64_t)j * kFwdKV * p.v_st.row, nv);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int kr = j * kFwdKV + sr + 32 * i;
-      kr = kr < lk ? kr : lk - 1;
-      kr = kr < 0 ? 0 : kr;
-      if (sd_ok) {
-        kreg[i] = *(const vec8<T>*)(kbase + (int64_t)kr * p.k_st.row + sc * 8);
-        vreg[i] = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
+      if (kDma) {
+        lds_t* dst = smem + kStage * kFwdTileBytes + (wave + 8 * i) * 1024;
+        buffer_load128_lds(rk, dst, voff_k[i]);
+        buffer_load128_lds(rv, dst + 2 * kFwdTileBytes, voff_v[i]);
       } else {
-        kreg[i] = zero8<T>();
-        vreg[i] = zero8<T>();
+        kreg[i] = buffer_load128<T>(rk, voff_k[i]);
+        vreg[i] = buffer_load128<T>(rv, voff_v[i]);
+        if (!sd_ok) {
+          kreg[i] = zero8<T>();
+          vreg[i] = zero8<T>();
+        }
       }
     }
   };
-  auto write_tile = [&](int buf) {
+  auto write_tile = [&](auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    if (!kDma) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = sr + 32 * i;
-      const int o = tile_off(row, sc);
-      lds_write128<T>(smem + buf * kFwdTileBytes + o, kreg[i]);
-      lds_write128<T>(smem + (2 + buf) * kFwdTileBytes + o, vreg[i]);
+      for (int i = 0; i < 2; ++i) {
+        const int o = tile_off(sr + 32 * i, sc);
+        lds_write128<T>(smem + kStage * kFwdTileBytes + o, kreg[i]);
+        lds_write128<T>(smem + (2 + kStage) * kFwdTileBytes + o, vreg[i]);
+      }
     }
   };
 
-  // ---- per-lane LDS offsets
+  // ---- per-lane LDS addresses (absolute, finished once; the loop only adds instruction immediates)
   // K fragment (A operand): row = 32t + l31, chunk = 2kk + g
   int koff[8];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) koff[kk] = tile_off(l31, 2 * kk + g);   // + t*32*256
+  for (int kk = 0; kk < 8; ++kk) {
+    koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);   // + t*32*256
+    pin_vgpr(koff[kk]);
+  }
   // V^T fragment via transpose read: rows rb = 32t + 16ks + 8hh + 4g (+ i>>2)
   int voff[4][2];
 #pragma unroll
   for (int dblk = 0; dblk < 4; ++dblk)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-      voff[dblk][hh] = (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
+    for (int hh = 0; hh < 2; ++hh) {
+      voff[dblk][hh] = lds_addr(smem) + (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
                        tr_lane_off(lane, dblk, (2 * hh + g) & 3);
+      pin_vgpr(voff[dblk][hh]);
+    }
 
   const float c = p.scale * kLog2e;
   float m = -INFINITY;
@@ -152,22 +181,26 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
-  // Always stage tile 0 (rows are clamped, so this is safe even when ntiles == 0): keeping the
-  // prologue unconditional leaves ONE path into the loop, on which every earlier global load
+  // Always stage tile 0 (rows past the end read as zero, so this is safe even when ntiles == 0): keeping
+  // the prologue unconditional leaves ONE path into the loop, on which every earlier global load
   // (Q fragment included) has provably landed — otherwise hipcc's waitcnt pass merges the
   // "nothing waited yet" path into the loop header and drains the tile prefetch (vmcnt(0))
   // in front of the first MFMA of every tile.
-  load_tile(0);
-  write_tile(0);
+  typedef std::integral_constant<int, 0> stage0_t;
+  typedef std::integral_constant<int, 1> stage1_t;
+  load_tile(0, stage0_t{});
+  write_tile(stage0_t{});
   wait_all_vmem();          // Q fragment loads too: nothing may stay pending into the loop
   __syncthreads();
-  if (RFA_FWD_PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int buf = j & 1;
-    lds_t* kb = smem + buf * kFwdTileBytes;
-    lds_t* vtile = smem + (2 + buf) * kFwdTileBytes;
-    if (j + 1 < ntiles) load_tile(j + 1);
+  // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by two), so every
+  // LDS address in here is a per-lane table entry plus an instruction immediate.
+  auto tile_step = [&](int j, auto stage) {
+    constexpr int kStage = decltype(stage)::value;
+    constexpr int kbo = kStage * kFwdTileBytes;            // K stage
+    constexpr int vbo = (2 + kStage) * kFwdTileBytes;      // V stage
+    typedef std::integral_constant<int, kStage ^ 1> next_t;
+    if (j + 1 < ntiles) load_tile(j + 1, next_t{});
 
     const int kt0 = j * kFwdKV;
     const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
@@ -178,17 +211,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
       {
         // 16 K fragments (2 sub-tiles x 8 k-steps), read kAhead ahead of their MFMA
         constexpr int kAhead = RFA_FWD_AHEAD;
         vec8<T> a[16];
+        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + kbo + (i >> 3) * 32 * kRowBytes); };
 #pragma unroll
-        for (int i = 0; i < kAhead; ++i) a[i] = lds_read128<T>(kb + (i >> 3) * 32 * kRowBytes + koff[i & 7]);
+        for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16)
-            a[i + kAhead] = lds_read128<T>(kb + ((i + kAhead) >> 3) * 32 * kRowBytes + koff[(i + kAhead) & 7]);
+          if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
           s[i >> 3] = mfma(a[i], qf[i & 7], s[i >> 3]);
         }
         // pin the issue order: kAhead reads, then read/MFMA pairs, then the MFMA tail
@@ -200,7 +232,6 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
       }
-      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
       // ---------------- mask ----------------
       const bool need_mask = (kt0 + kFwdKV > lk) || (p.causal && kt0 + kFwdKV - 1 > qw0 + off);
       if (need_mask) {
@@ -249,55 +280,27 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       lsum += psum;
 
       // ---------------- O^T += V^T P^T ----------------
-      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#if RFA_FWD_PIN_PV
-      {
-        // 16 MFMAs (i = [t][ks2][dblk]), each fed by two transpose reads issued kAhead MFMAs ahead
-        vec8<T> pb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pb[u] = pack8<T>(s[u >> 1], 8 * (u & 1));
-        constexpr int kAhead = RFA_FWD_PIN_PV;
-        vec8<T> a[16];
-        auto frag = [&](int i) {
-          lds_t* vb = vtile + (32 * (i >> 3) + 16 * ((i >> 2) & 1)) * kRowBytes;
-          vec4<T> lo = lds_read_tr<T>(vb + voff[i & 3][0]);
-          vec4<T> hi = lds_read_tr<T>(vb + voff[i & 3][1]);
-          return concat<T>(lo, hi);
-        };
-#pragma unroll
-        for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16) a[i + kAhead] = frag(i + kAhead);
-          o[i & 3] = mfma(a[i], pb[i >> 2], o[i & 3]);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
-#pragma unroll
-        for (int i = 0; i < 16 - kAhead; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
-      }
-#else
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> pb = pack8<T>(s[t], 8 * ks2);
-          lds_t* vb = vtile + (32 * t + 16 * ks2) * kRowBytes;
+          const int imm = vbo + (32 * t + 16 * ks2) * kRowBytes;
 #pragma unroll
           for (int dblk = 0; dblk < 4; ++dblk) {
-            vec4<T> lo = lds_read_tr<T>(vb + voff[dblk][0]);
-            vec4<T> hi = lds_read_tr<T>(vb + voff[dblk][1]);
+            vec4<T> lo = lds_read_tr<T>(lds_ptr(voff[dblk][0]) + imm);
+            vec4<T> hi = lds_read_tr<T>(lds_ptr(voff[dblk][1]) + imm);
             o[dblk] = mfma(concat<T>(lo, hi), pb, o[dblk]);
           }
         }
-#endif
-      if (RFA_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
-    if (j + 1 < ntiles) write_tile(buf ^ 1);
+    if (j + 1 < ntiles) write_tile(next_t{});
+    if (kDma) wait_all_vmem();                           // the DMA of tile j+1 must have landed before the barrier
     __syncthreads();
+  };
+  for (int j = 0; j < ntiles; j += 2) {
+    tile_step(j, stage0_t{});
+    if (j + 1 < ntiles) tile_step(j + 1, stage1_t{});
   }
 
   // ---------------- epilogue ----------------
