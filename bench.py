@@ -131,10 +131,19 @@ def main():
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ.setdefault("MASTER_PORT", "29541")
     # one process per GPU over RCCL ("nccl" on ROCm); a single process has nothing to exchange
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    else:
-        dist.init_process_group("gloo", rank=0, world_size=1)
+    # (libgloo / librccl print connection banners on fd 1: keep stdout for the ONE JSON line)
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=0, world_size=1)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from ring_flash_attn import zigzag_ring_flash_attn_kvpacked_func as fn

@@ -70,7 +70,7 @@ def build_lib(force=False):
     if not force and not _stale(LIB, deps):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wno-unused-result"]
+           "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-inline-asm"]
     cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
     cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
     cmd += ["-o", LIB]

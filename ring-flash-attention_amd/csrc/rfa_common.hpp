@@ -198,9 +198,35 @@ template <typename T>
 __device__ __forceinline__ vec8<T> buffer_load128(buf_rsrc_t r, int voffset) {
   return __builtin_bit_cast(vec8<T>, __builtin_amdgcn_raw_buffer_load_b128(r, voffset, 0, 0));
 }
-// global -> LDS without staging registers: lane L's 16 bytes land at lds_wave_base + 16 L
-__device__ __forceinline__ void buffer_load128_lds(buf_rsrc_t r, lds_t* lds_wave_base, int voffset) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voffset, 0, 0, 0);
+// global -> LDS without staging registers (buffer_load_dwordx4 ... lds): lane L's 16 bytes land at
+// lds_wave_base + 16 L; out-of-range lanes write zeros.  Issued through inline asm ON PURPOSE: hipcc's
+// waitcnt pass cannot tell which LDS stage a DMA fills and protects every later ds_read with vmcnt(0),
+// which serialises a ring deeper than two stages.  Hidden from it, the kernels place their own counted
+// `s_waitcnt vmcnt(n)` (wait_vmem<n>) in front of the barrier that publishes a stage.  Compiler-issued
+// vector memory operations stay correct: vmcnt retires in order, extra outstanding DMAs can only make
+// the compiler's own waits longer, never shorter.
+struct dma_rsrc_t {
+  i32x4 w;   // {base[31:0], base[47:32], num_records (bytes), flags}
+};
+__device__ __forceinline__ dma_rsrc_t make_dma_rsrc(const void* base, int num_bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  dma_rsrc_t r;
+  r.w[0] = (int)(unsigned)a;
+  r.w[1] = (int)(unsigned)(a >> 32) & 0xffff;
+  r.w[2] = num_bytes;
+  r.w[3] = 0x00020000;
+  return r;
+}
+__device__ __forceinline__ void dma_load128(dma_rsrc_t r, int lds_wave_base, int voffset) {
+  asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+               :
+               : "v"(voffset), "s"(r.w), "s"(lds_wave_base)
+               : "m0");
+}
+// s_waitcnt vmcnt(n), n < 16, lgkmcnt / expcnt untouched
+template <int n>
+__device__ __forceinline__ void wait_vmem() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | n);
 }
 __device__ __forceinline__ float buffer_load32(buf_rsrc_t r, int voffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 0));

@@ -35,13 +35,17 @@ constexpr int kFwdThreads = kFwdWaves * 64;
 constexpr int kFwdQRows = kFwdWaves * 32;   // 256 query rows per workgroup
 constexpr int kFwdKV = 64;                  // keys per tile
 constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB
-constexpr int kFwdSmem = 4 * kFwdTileBytes;                 // K[2] + V[2] = 64 KiB
+#ifndef RFA_FWD_STAGES
+#define RFA_FWD_STAGES 2     // LDS ring depth: tile j+STAGES-1 is in flight (DMA) while tile j is computed
+#endif
+constexpr int kFwdStages = RFA_FWD_STAGES;
+constexpr int kFwdSmem = 2 * kFwdStages * kFwdTileBytes;    // K[stages] + V[stages] (96 KiB at 3)
 
 template <typename T, bool kFullD>
 __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
-  // LDS map: K tile buffers at [0, 2*tile), V tile buffers at [2*tile, 4*tile)
+  // LDS map: K stages at [0, stages*tile), V stages behind them
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,15 +127,20 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     rows = rows < kFwdKV ? rows : kFwdKV;
     const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
     const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
-    const buf_rsrc_t rk = make_rsrc(kbase + (int64_t)j * kFwdKV * p.k_st.row, nk);
-    const buf_rsrc_t rv = make_rsrc(vbase + (int64_t)j * kFwdKV * p.v_st.row, nv);
+    const T* kt = kbase + (int64_t)j * kFwdKV * p.k_st.row;
+    const T* vt = vbase + (int64_t)j * kFwdKV * p.v_st.row;
+    if (kDma) {
+      const dma_rsrc_t rk = make_dma_rsrc(kt, nk), rv = make_dma_rsrc(vt, nv);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (kDma) {
-        lds_t* dst = smem + kStage * kFwdTileBytes + (wave + 8 * i) * 1024;
-        buffer_load128_lds(rk, dst, voff_k[i]);
-        buffer_load128_lds(rv, dst + 2 * kFwdTileBytes, voff_v[i]);
-      } else {
+      for (int i = 0; i < 2; ++i) {
+        const int dst = lds_addr(smem) + kStage * kFwdTileBytes + (wave + 8 * i) * 1024;
+        dma_load128(rk, dst, voff_k[i]);
+        dma_load128(rv, dst + kFwdStages * kFwdTileBytes, voff_v[i]);
+      }
+    } else {
+      const buf_rsrc_t rk = make_rsrc(kt, nk), rv = make_rsrc(vt, nv);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
         kreg[i] = buffer_load128<T>(rk, voff_k[i]);
         vreg[i] = buffer_load128<T>(rv, voff_v[i]);
         if (!sd_ok) {
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       for (int i = 0; i < 2; ++i) {
         const int o = tile_off(sr + 32 * i, sc);
         lds_write128<T>(smem + kStage * kFwdTileBytes + o, kreg[i]);
-        lds_write128<T>(smem + (2 + kStage) * kFwdTileBytes + o, vreg[i]);
+        lds_write128<T>(smem + (kFwdStages + kStage) * kFwdTileBytes + o, vreg[i]);
       }
     }
   };
@@ -186,21 +195,24 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   // (Q fragment included) has provably landed — otherwise hipcc's waitcnt pass merges the
   // "nothing waited yet" path into the loop header and drains the tile prefetch (vmcnt(0))
   // in front of the first MFMA of every tile.
-  typedef std::integral_constant<int, 0> stage0_t;
-  typedef std::integral_constant<int, 1> stage1_t;
-  load_tile(0, stage0_t{});
-  write_tile(stage0_t{});
-  wait_all_vmem();          // Q fragment loads too: nothing may stay pending into the loop
+  // The DMA path keeps kFwdStages - 1 tiles in flight; the register path (D < 128) only one.
+  constexpr int kDist = kDma ? kFwdStages - 1 : 1;
+  load_tile(0, std::integral_constant<int, 0>{});
+  write_tile(std::integral_constant<int, 0>{});
+  wait_all_vmem();          // Q fragment loads too: nothing the compiler tracks may stay pending into the loop
   __syncthreads();
+  if (kDist == 2) load_tile(1, std::integral_constant<int, 1>{});   // (rows past the end: descriptor range 0)
 
-  // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by two), so every
-  // LDS address in here is a per-lane table entry plus an instruction immediate.
+  // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by the ring depth),
+  // so every LDS address in here is a per-lane table entry plus an instruction immediate.
   auto tile_step = [&](int j, auto stage) {
     constexpr int kStage = decltype(stage)::value;
-    constexpr int kbo = kStage * kFwdTileBytes;            // K stage
-    constexpr int vbo = (2 + kStage) * kFwdTileBytes;      // V stage
-    typedef std::integral_constant<int, kStage ^ 1> next_t;
-    if (j + 1 < ntiles) load_tile(j + 1, next_t{});
+    constexpr int kbo = kStage * kFwdTileBytes;                   // K stage
+    constexpr int vbo = (kFwdStages + kStage) * kFwdTileBytes;    // V stage
+    typedef std::integral_constant<int, (kStage + kDist) % kFwdStages> fill_t;   // stage refilled now
+    typedef std::integral_constant<int, (kStage + 1) % kFwdStages> next_t;
+    const bool more = j + kDist < ntiles;
+    if (more) load_tile(j + kDist, fill_t{});
 
     const int kt0 = j * kFwdKV;
     const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
@@ -294,13 +306,25 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
           }
         }
     }
-    if (j + 1 < ntiles) write_tile(next_t{});
-    if (kDma) wait_all_vmem();                           // the DMA of tile j+1 must have landed before the barrier
+    if (!kDma && more) write_tile(next_t{});
+    if (kDma) {
+      // tile j+1 must have landed before the barrier; the 4 DMA instructions of tile j+2 (if issued) may fly on
+      if (kDist == 2 && more) wait_vmem<4>();
+      else wait_all_vmem();
+    }
     __syncthreads();
   };
-  for (int j = 0; j < ntiles; j += 2) {
-    tile_step(j, stage0_t{});
-    if (j + 1 < ntiles) tile_step(j + 1, stage1_t{});
+  if (kFwdStages == 3) {
+    for (int j = 0; j < ntiles; j += 3) {
+      tile_step(j, std::integral_constant<int, 0>{});
+      if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
+      if (j + 2 < ntiles) tile_step(j + 2, std::integral_constant<int, 2 % kFwdStages>{});
+    }
+  } else {
+    for (int j = 0; j < ntiles; j += 2) {
+      tile_step(j, std::integral_constant<int, 0>{});
+      if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
+    }
   }
 
   // ---------------- epilogue ----------------

@@ -20,7 +20,7 @@ def main():
         out = os.path.join(ROOT, "build", "variants", name)
         os.makedirs(out, exist_ok=True)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-               "-Wno-unused-result"] + flags + [os.path.join(CSRC, s) for s in SRCS] + \
+               "-Wno-unused-result", "-Wno-inline-asm"] + flags + [os.path.join(CSRC, s) for s in SRCS] + \
               ["-x", "hip", os.path.join(CSRC, "rfa_api.cpp"), "-o", os.path.join(out, "librfa_hip.so")]
         procs.append((name, subprocess.Popen(cmd)))
         names.append(name)
