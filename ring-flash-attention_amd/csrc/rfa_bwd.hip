@@ -137,12 +137,14 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
     const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
     const buf_rsrc_t rk = make_rsrc(kbase + (int64_t)j * kDqKV * p.k_st.row, nk);
     const buf_rsrc_t rv = make_rsrc(vbase + (int64_t)j * kDqKV * p.v_st.row, nv);
+    const dma_rsrc_t dk = make_dma_rsrc(kbase + (int64_t)j * kDqKV * p.k_st.row, nk);
+    const dma_rsrc_t dv = make_dma_rsrc(vbase + (int64_t)j * kDqKV * p.v_st.row, nv);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (kDma) {
-        lds_t* dst = smem + kStage * kDqTileBytes + (wave + 8 * i) * 1024;
-        buffer_load128_lds(rk, dst, voff_k[i]);
-        buffer_load128_lds(rv, dst + 2 * kDqTileBytes, voff_v[i]);
+        const int dst = lds_addr(smem) + kStage * kDqTileBytes + (wave + 8 * i) * 1024;
+        dma_load128(dk, dst, voff_k[i]);
+        dma_load128(dv, dst + 2 * kDqTileBytes, voff_v[i]);
       } else {
         kreg[i] = buffer_load128<T>(rk, voff_k[i]);
         vreg[i] = buffer_load128<T>(rv, voff_v[i]);
@@ -440,12 +442,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
     const buf_rsrc_t rq = make_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
     const buf_rsrc_t rdo = make_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
+    const dma_rsrc_t dq_ = make_dma_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
+    const dma_rsrc_t ddo = make_dma_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (kDma) {
-        lds_t* dst = smem + dma_stage + (wave + 8 * i) * 1024;
-        buffer_load128_lds(rq, dst, voff_q[i]);
-        buffer_load128_lds(rdo, dst + kOffDo, voff_do[i]);
+        const int dst = lds_addr(smem) + dma_stage + (wave + 8 * i) * 1024;
+        dma_load128(dq_, dst, voff_q[i]);
+        dma_load128(ddo, dst + kOffDo, voff_do[i]);
       } else {
         qreg[i] = buffer_load128<T>(rq, voff_q[i]);
         doreg[i] = buffer_load128<T>(rdo, voff_do[i]);
