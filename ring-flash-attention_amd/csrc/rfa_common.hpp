@@ -211,16 +211,18 @@ struct dma_rsrc_t {
 __device__ __forceinline__ dma_rsrc_t make_dma_rsrc(const void* base, int num_bytes) {
   const unsigned long long a = (unsigned long long)base;
   dma_rsrc_t r;
-  r.w[0] = (int)(unsigned)a;
-  r.w[1] = (int)(unsigned)(a >> 32) & 0xffff;
-  r.w[2] = num_bytes;
+  // readfirstlane: the descriptor must sit in SGPRs even where the compiler's uniformity analysis gives
+  // up (e.g. values defined under a wave-uniform role branch); free when the value already is scalar
+  r.w[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.w[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+  r.w[2] = __builtin_amdgcn_readfirstlane(num_bytes);
   r.w[3] = 0x00020000;
   return r;
 }
 __device__ __forceinline__ void dma_load128(dma_rsrc_t r, int lds_wave_base, int voffset) {
   asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                :
-               : "v"(voffset), "s"(r.w), "s"(lds_wave_base)
+               : "v"(voffset), "s"(r.w), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
                : "m0");
 }
 // s_waitcnt vmcnt(n), n < 16, lgkmcnt / expcnt untouched
