@@ -30,9 +30,13 @@
 
 namespace rfa {
 
-constexpr int kFwdWaves = 8;
+#ifndef RFA_FWD_WAVES
+#define RFA_FWD_WAVES 8      // waves per workgroup (32 q rows each); 4 -> two independent workgroups per CU
+#endif
+constexpr int kFwdWaves = RFA_FWD_WAVES;
+constexpr int kFwdShare = 16 / kFwdWaves;   // 4-row groups of a 64-row tile staged by each wave
 constexpr int kFwdThreads = kFwdWaves * 64;
-constexpr int kFwdQRows = kFwdWaves * 32;   // 256 query rows per workgroup
+constexpr int kFwdQRows = kFwdWaves * 32;   // query rows per workgroup
 constexpr int kFwdKV = 64;                  // keys per tile
 constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB
 #ifndef RFA_FWD_STAGES
@@ -102,20 +106,20 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   // the tile advance lives in the scalar descriptor, rows past the end of the sequence read as zero.
   // With D == 128 the tile goes global -> LDS directly (buffer_load ... lds, no staging registers and no
   // LDS-write instructions): a wave-instruction fills 64 consecutive 16-byte slots = 4 tile rows, so lane
-  // L of the DMA for row group c = wave + 8 i lands in row 4c + L/16, physical chunk L%16 and must FETCH
+  // L of the DMA for row group c = wave + kFwdWaves i lands in row 4c + L/16, physical chunk L%16 and must FETCH
   // the logical chunk the swizzle puts there.  D < 128 needs the chunks beyond D zeroed and goes
   // global -> registers -> LDS (issue early / write late).
   constexpr bool kDma = kFullD;
   const int sc = tid & 15;
   const int sr = tid >> 4;
   const bool sd_ok = kFullD || sc * 8 < p.D;
-  vec8<T> kreg[2], vreg[2];
-  int voff_k[2], voff_v[2];
+  vec8<T> kreg[kFwdShare], vreg[kFwdShare];
+  int voff_k[kFwdShare], voff_v[kFwdShare];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = sr + 32 * i, chunk = sc;
+  for (int i = 0; i < kFwdShare; ++i) {
+    int row = sr + 4 * kFwdWaves * i, chunk = sc;
     if (kDma) {
-      row = 4 * (wave + 8 * i) + (lane >> 4);
+      row = 4 * (wave + kFwdWaves * i) + (lane >> 4);
       chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
     }
     voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
@@ -132,15 +136,15 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     if (kDma) {
       const dma_rsrc_t rk = make_dma_rsrc(kt, nk), rv = make_dma_rsrc(vt, nv);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int dst = lds_addr(smem) + kStage * kFwdTileBytes + (wave + 8 * i) * 1024;
+      for (int i = 0; i < kFwdShare; ++i) {
+        const int dst = lds_addr(smem) + kStage * kFwdTileBytes + (wave + kFwdWaves * i) * 1024;
         dma_load128(rk, dst, voff_k[i]);
         dma_load128(rv, dst + kFwdStages * kFwdTileBytes, voff_v[i]);
       }
     } else {
       const buf_rsrc_t rk = make_rsrc(kt, nk), rv = make_rsrc(vt, nv);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < kFwdShare; ++i) {
         kreg[i] = buffer_load128<T>(rk, voff_k[i]);
         vreg[i] = buffer_load128<T>(rv, voff_v[i]);
         if (!sd_ok) {
@@ -154,8 +158,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     constexpr int kStage = decltype(stage)::value;
     if (!kDma) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int o = tile_off(sr + 32 * i, sc);
+      for (int i = 0; i < kFwdShare; ++i) {
+        const int o = tile_off(sr + 4 * kFwdWaves * i, sc);
         lds_write128<T>(smem + kStage * kFwdTileBytes + o, kreg[i]);
         lds_write128<T>(smem + (kFwdStages + kStage) * kFwdTileBytes + o, vreg[i]);
       }
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     if (!kDma && more) write_tile(next_t{});
     if (kDma) {
       // tile j+1 must have landed before the barrier; the 4 DMA instructions of tile j+2 (if issued) may fly on
-      if (kDist == 2 && more) wait_vmem<4>();
+      if (kDist == 2 && more) wait_vmem<2 * kFwdShare>();
       else wait_all_vmem();
     }
     __syncthreads();
