@@ -131,8 +131,9 @@ typedef struct {
   float *dq_acc, *dk_acc, *dv_acc;
   rfa_strides dq_acc_st, dk_acc_st, dv_acc_st;
   int32_t acc_init;
-  /* workspace for per-q-head dK/dV partials, io dtype, 2 * B*Sk_total*H*D elements
-   * (rfa_bwd_workspace_bytes).  May be NULL iff H == Hk and dk_acc == NULL. */
+  /* workspace for dK/dV partials (already summed over the query heads of a K/V group), io dtype,
+   * 2 * total_k*Hk*D elements (rfa_bwd_workspace_bytes).  May be NULL iff dk_acc == NULL and
+   * phases == 0. */
   void *workspace;
   const int32_t *cu_seqlens_q, *cu_seqlens_k;
   int32_t q_half, k_half;
@@ -142,9 +143,9 @@ typedef struct {
   int32_t causal;
   int32_t deterministic; /* accepted; this implementation is always deterministic */
   int32_t dtype;
-  /* 0 = everything.  RFA_BWD_COMPUTE: dQ + per-head dK/dV partials into `workspace` only;
-   * RFA_BWD_REDUCE: group-sum the partials of a previous COMPUTE call into dk/dv or
-   * dk_acc/dv_acc.  Splitting lets a ring step overlap the compute with the arrival of the
+  /* 0 = everything.  RFA_BWD_COMPUTE: dQ + dK/dV partials into `workspace` only;
+   * RFA_BWD_REDUCE: add / copy the partials of a previous COMPUTE call into dk_acc/dv_acc or
+   * dk/dv.  Splitting lets a ring step overlap the compute with the arrival of the
    * dk/dv accumulators it will add into (zigzag_ring_flash_attn.py:172-187).  With phases != 0
    * the workspace is always required. */
   int32_t phases;

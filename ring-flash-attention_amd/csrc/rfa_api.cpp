@@ -104,13 +104,17 @@ int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {
   return launch_preprocess(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
 }
 
+// The dK/dV kernel sums the query heads of a K/V group itself, so GQA needs no scratch.  A workspace
+// (bf16/fp16 partials, (rows, Hk, D) x 2) is only used when the result is ADDED to fp32 accumulators or
+// when compute and reduction are issued as two phases (ring steps: compute overlaps the arrival of the
+// accumulators).
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
-  return a->H != a->Hk || a->dk_acc != nullptr || a->phases != RFA_BWD_ALL;
+  return a->dk_acc != nullptr || a->phases != RFA_BWD_ALL;
 }
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
-  return 2 * a->total_k * (int64_t)a->H * a->D * 2;
+  return 2 * a->total_k * (int64_t)a->Hk * a->D * 2;
 }
 
 int rfa_bwd(const rfa_bwd_args* a, void* stream) {
@@ -156,12 +160,12 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
 
   Strides ws_st{};
   if (ws) {
-    // partials: (rows, H, D) contiguous; dense rows = b*Sk + row (own batch stride)
+    // partials: (rows, Hk, D) contiguous; dense rows = b*Sk + row (own batch stride)
     ws_st.head = a->D;
-    ws_st.row = (int64_t)a->H * a->D;
-    ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->H * a->D;
+    ws_st.row = (int64_t)a->Hk * a->D;
+    ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->Hk * a->D;
     p.dk = a->workspace;
-    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->H * a->D * 2;
+    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->Hk * a->D * 2;
     p.dk_st = ws_st; p.dv_st = ws_st;
   } else {
     p.dk = a->dk; p.dv = a->dv;
@@ -179,7 +183,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       r.src = which ? p.dv : p.dk;
       r.src_st = ws_st;
       r.cu_k = a->cu_seqlens_k;
-      r.B = a->B; r.Hk = a->Hk; r.G = a->H / a->Hk; r.D = a->D; r.Sk = a->Sk;
+      r.B = a->B; r.Hk = a->Hk; r.G = 1; r.D = a->D; r.Sk = a->Sk;   // groups are already summed
       r.k_half = a->k_half; r.acc_init = a->acc_init ? 1 : 0;
       if (a->dk_acc) {
         r.dst_acc = which ? a->dv_acc : a->dk_acc;

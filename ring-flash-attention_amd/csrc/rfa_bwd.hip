@@ -348,11 +348,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int G = p.H / p.Hk;
   const int hk = idx % p.Hk;
   idx /= p.Hk;
-  const int gq = idx % G;
-  idx /= G;
   const int kblk = idx % p.nkblk;
   const int b = idx / p.nkblk;
-  const int h = hk * G + gq;
+  const int h0 = hk * G;                              // the G query heads h0 .. h0+G-1 share this K/V head
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
   const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
@@ -367,11 +365,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 
   const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
   const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
-  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + qs.row0 * p.q_st.row + (int64_t)h * p.q_st.head;
-  const T* dobase = (const T*)p.dout + qbatch * p.dout_st.batch + qs.row0 * p.dout_st.row +
-                    (int64_t)h * p.dout_st.head;
-  const float* lsebase = p.lse + qbatch * p.lse_batch + (int64_t)h * p.lse_head + qs.row0;
-  const float* dltbase = p.delta + qbatch * p.delta_batch + (int64_t)h * p.delta_head + qs.row0;
+  const T* qbase0 = (const T*)p.q + qbatch * p.q_st.batch + qs.row0 * p.q_st.row + (int64_t)h0 * p.q_st.head;
+  const T* dobase0 = (const T*)p.dout + qbatch * p.dout_st.batch + qs.row0 * p.dout_st.row +
+                     (int64_t)h0 * p.dout_st.head;
+  const float* lsebase0 = p.lse + qbatch * p.lse_batch + (int64_t)h0 * p.lse_head + qs.row0;
+  const float* dltbase0 = p.delta + qbatch * p.delta_batch + (int64_t)h0 * p.delta_head + qs.row0;
 
   int qfirst = 0;
   if (p.causal) {
@@ -434,8 +432,21 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     voff_q[i] = (row * (int)p.q_st.row + chunk * 8) * 2;
     voff_do[i] = (row * (int)p.dout_st.row + chunk * 8) * 2;
   }
+  // The workgroup streams the Q/dO tiles jt0 .. jt1-1 of ALL G query heads of its K/V head, one head after
+  // the other, through the same two LDS stages (no drain between heads): dK/dV of the group are summed in
+  // the fp32 accumulators and written once — no per-head partials, no group-reduction pass.
   int dma_stage = 0;                                  // LDS stage the next load_tile() fills (scalar)
-  auto load_tile = [&](int j) {
+  int ld_g = 0, ld_j = jt0;                           // (head in group, tile) the next load_tile() fetches
+  auto load_tile = [&]() {
+    const int j = ld_j;
+    const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
+    const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
+    const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
+    const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
+    if (++ld_j >= jt1) {
+      ld_j = jt0;
+      ++ld_g;
+    }
     int rows = lq - j * kKvQ;
     rows = rows < kKvQ ? rows : kKvQ;
     const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
-  load_tile(jt0);
+  load_tile();                                         // (jt0 >= jt1: zero rows, nothing is read)
   write_tile();
   wq ^= kKvTileBytes;
   ws ^= kKvStatBytes;
@@ -511,8 +522,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #if RFA_KV_PRIO
   if (par == 0) __builtin_amdgcn_s_setprio(2);
 #endif
-  for (int j = jt0; j < jt1; ++j) {
-    if (j + 1 < jt1) load_tile(j + 1);
+  const int ntile = jt1 > jt0 ? (jt1 - jt0) * G : 0;
+  int j = jt0;
+  for (int f = 0; f < ntile; ++f) {
+    if (f + 1 < ntile) load_tile();
     const int qs0 = j * kKvQ + 32 * t;
     const bool active = (kw0 < lk) && (qs0 < lq) && !(p.causal && qs0 + 31 + off < kw0);
     if (active) {
@@ -608,7 +621,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #endif
       }
     }
-    if (j + 1 < jt1) write_tile();
+    if (f + 1 < ntile) write_tile();
+    if (++j >= jt1) j = jt0;
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
     tq[0] ^= kKvTileBytes;
     tq[1] ^= kKvTileBytes;
@@ -642,10 +656,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   if (krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
   if (par == 0) {
-    T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)h * p.dk_st.head;
+    T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)hk * p.dk_st.head;
     store_rows16<T, kFullD>(dkb, dk, p.scale, g, p.D, true);
   } else {
-    T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)h * p.dv_st.head;
+    T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)hk * p.dv_st.head;
     store_rows16<T, kFullD>(dvb, dv, 1.f, g, p.D, true);
   }
 }
@@ -670,7 +684,7 @@ static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)dkdv_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize, kKvSmem);
     attr_done = true;
   }
-  const int64_t nblocks = (int64_t)p.nkblk * p.H * p.B;
+  const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B;      // one workgroup per (key block, K/V head)
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL((dkdv_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -78,7 +78,7 @@ class HipBackend:
             raise TypeError(f"ring_flash_attn: unsupported dtype {t.dtype} (bf16/fp16 only)") from None
 
     def _workspace(self, device, nbytes):
-        """Per-device grow-only scratch for the per-q-head dK/dV partials (caller-owned memory
+        """Per-device grow-only scratch for the dK/dV partials of accumulate / two-phase calls (caller-owned memory
         from torch's caching allocator; the C library itself never allocates)."""
         key = (device.type, device.index)
         buf = self._ws.get(key)

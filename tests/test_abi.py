@@ -81,9 +81,10 @@ def test_argument_errors_without_device(built):
     b.B, b.H, b.Hk, b.D, b.Sq, b.Sk, b.dtype = 1, 4, 2, 64, 8, 8, 0
     assert lib.rfa_bwd(C.byref(b), None) == -1
     b.total_k = 8
-    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 2 * 8 * 4 * 64 * 2
-    b.Hk = 4
-    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 0
+    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 0       # GQA groups are summed inside the kernel
+    b.phases = 1                                              # two-phase call: (rows, Hk, D) x 2 partials
+    assert lib.rfa_bwd_workspace_bytes(C.byref(b)) == 2 * 8 * 2 * 64 * 2
+    b.phases = 0
 
 
 def test_product_path_has_no_cpu_fallback(built, single_rank_group):
