@@ -32,7 +32,7 @@ def _cmp(name, got, ref, tol, errs):
         errs.append(f"{name}: max|diff| {diff:.3e} > {lim:.3e}")
 
 
-def run_rank(rank, W, port, names, use_hip, ret):
+def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.set_num_threads(2)
@@ -40,6 +40,20 @@ def run_rank(rank, W, port, names, use_hip, ret):
         import make_golden as MG
         import ring_flash_attn as R
         from ring_flash_attn import backend
+
+        if via_reference:
+            # INTEGRATION.md route B: the UNMODIFIED reference schedules on top of the shipped `flash_attn`
+            # compatibility package (whose kernels are whatever backend is installed below)
+            import types
+
+            from oracle.reference_harness import load_reference
+
+            ref_mods = load_reference(provider="shim")
+            R = types.SimpleNamespace()
+            for mod in ref_mods.values():
+                for name in dir(mod):
+                    if name.endswith("_func") or name == "llama3_flash_attn_prepare_cu_seqlens":
+                        setattr(R, name, getattr(mod, name))
 
         golden = torch.load(os.path.join(ROOT, "tests", "golden", "ring_golden.pt"), weights_only=False)
         if use_hip:
@@ -95,12 +109,12 @@ def run_rank(rank, W, port, names, use_hip, ret):
         ret[rank] = ["EXC: " + traceback.format_exc()]
 
 
-def run_world(W, names, use_hip, port):
+def run_world(W, names, use_hip, port, via_reference=False):
     import torch.multiprocessing as mp
 
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(run_rank, args=(W, port, names, use_hip, ret), nprocs=W, join=True)
+    mp.spawn(run_rank, args=(W, port, names, use_hip, ret, via_reference), nprocs=W, join=True)
     errs = []
     for r in range(W):
         errs += list(ret.get(r, [f"rank {r} produced no result"]))

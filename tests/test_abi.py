@@ -140,3 +140,40 @@ def test_prepare_cu_seqlens_golden(golden):
         cq, ck, mq, mk, sl = llama3_flash_attn_prepare_cu_seqlens(cu, g["causal"], g["rank"], g["W"])
         assert cq.dtype == torch.int32 and cq.tolist() == g["cu_q"] and ck.tolist() == g["cu_k"]
         assert (mq, mk) == (g["max_q"], g["max_k"]) and (sl.start, sl.stop) == tuple(g["k_slice"])
+
+
+def test_flash_attn_shim_surface(built):
+    """The shipped `flash_attn` package exposes what the reference imports, in the form its
+    `get_default_args` (utils.py:13-29) inspects: plain functions, flash_attn >= 2.7 parameter names
+    (`window_size_left/right`, not `window_size`), `softcap` defaulting to 0.0."""
+    import inspect
+
+    import flash_attn
+    from flash_attn import flash_attn_interface as F
+
+    for name in ("flash_attn_func", "flash_attn_kvpacked_func", "flash_attn_qkvpacked_func",
+                 "flash_attn_varlen_func", "flash_attn_varlen_kvpacked_func", "flash_attn_varlen_qkvpacked_func"):
+        assert callable(getattr(flash_attn, name))
+    want = {
+        "_flash_attn_forward": ["q", "k", "v", "dropout_p", "softmax_scale", "causal", "window_size_left",
+                                "window_size_right", "softcap", "alibi_slopes", "return_softmax"],
+        "_flash_attn_backward": ["dout", "q", "k", "v", "out", "softmax_lse", "dq", "dk", "dv", "dropout_p",
+                                 "softmax_scale", "causal", "window_size_left", "window_size_right", "softcap",
+                                 "alibi_slopes", "deterministic", "rng_state"],
+    }
+    for name, args in want.items():
+        fn = getattr(F, name)
+        assert inspect.isfunction(fn)
+        spec = inspect.getfullargspec(fn)
+        assert spec.args == args, (name, spec.args)
+    for name in ("_flash_attn_varlen_forward", "_flash_attn_varlen_backward"):
+        spec = inspect.getfullargspec(getattr(F, name))
+        for a in ("cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "window_size_left", "softcap"):
+            assert a in spec.args, (name, a)
+    import torch
+
+    q = torch.zeros(1, 8, 2, 64, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        F._flash_attn_forward(q, q, q, 0.1, 0.125, True)
+    with pytest.raises(NotImplementedError):
+        F._flash_attn_forward(q, q, q, 0.0, 0.125, True, softcap=30.0)

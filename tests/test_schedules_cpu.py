@@ -22,6 +22,20 @@ def test_schedules_match_reference_golden(W):
     assert not errs, "\n".join(errs)
 
 
+def test_unmodified_reference_runs_on_the_flash_attn_shim():
+    """INTEGRATION.md route B: the reference's own schedule code (loaded unmodified from /root/reference)
+    on top of the shipped `flash_attn` compatibility package reproduces the golden vectors.  Build
+    container only (the reference tree does not travel); the kernels underneath are the CPU oracle
+    here — the same shim over the HIP kernels is covered by tests/test_gpu_flash_attn_shim.py."""
+    from oracle import reference_harness
+
+    if not reference_harness.available():
+        pytest.skip("/root/reference not present")
+    names = [n for n, c in MG.CASES.items() if c["W"] == 2]
+    errs = RW.run_world(2, names, use_hip=False, port=free_port(), via_reference=True)
+    assert not errs, "\n".join(errs)
+
+
 def test_ringcomm_guards(single_rank_group):
     """RingComm keeps the reference's state guards (utils.py:129-136)."""
     from ring_flash_attn.utils import RingComm
