@@ -15,14 +15,44 @@ MI355X-first differences:
   * backward: delta = rowsum(dO*O) once per call; dQ accumulates in fp32 inside the dQ kernel;
     dK/dV partials are group-summed straight into the travelling fp32 accumulators, split in
     two phases so the kernels overlap the arrival of those accumulators;
-  * world_size == 1 short-circuits to a single kernel writing q.dtype directly.
+  * world_size == 1 short-circuits to a single kernel writing q.dtype directly;
+  * K/V exchange is mesh-aware by default (RFA_ZIGZAG_EXCHANGE=gather): ONE all-gather of K and V,
+    overlapped with the local causal block, replaces the W-1 neighbour hops of the forward, and in
+    the backward one all-gather + one fp32 reduce-scatter of the per-chunk dK/dV contributions
+    replace 2(W-1)+W hops.  A neighbour ring drives 1 of a rank's 7 xGMI links and sits on the
+    critical path once per step (33.5 MB bf16 K/V per step against a 0.5 ms attention step at the
+    headline shape; 100 MB incl. fp32 dK/dV in the backward); the collectives use the
+    whole mesh and put one transfer, not W, on the critical path.  The per-step kernels, their
+    arguments and the merge order are exactly those of the ring form (the forward is bit-identical;
+    dK/dV differ by fp32 summation order only).  RFA_ZIGZAG_EXCHANGE=ring restores the reference's
+    hop-by-hop protocol (same results, kept for networks where a ring is the better map).
 """
+import os
+
 import torch
 
 from . import _C
 from .backend import get_backend
-from .utils import RingComm
+from .utils import AllGatherComm, RingComm, reduce_scatter
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
+
+
+def _exchange_mode() -> str:
+    mode = os.environ.get("RFA_ZIGZAG_EXCHANGE", "gather").lower()
+    if mode not in ("gather", "ring"):
+        raise ValueError(f"RFA_ZIGZAG_EXCHANGE must be 'gather' or 'ring', got {mode!r}")
+    return mode
+
+
+def _gather_kv(comm_group, k, v, world):
+    """posts the all-gather of k and v; returns (handle, k_all, v_all) with *_all[(src rank)] views"""
+    gather = AllGatherComm(comm_group)
+    # (world*B, ...) for the collective (the concatenated form every backend accepts), (world, B, ...) to index
+    k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
+    v_cat = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+    gather.all_gather(k_cat, k.contiguous())
+    gather.all_gather(v_cat, v.contiguous())
+    return gather, k_cat.view((world,) + tuple(k.shape)), v_cat.view((world,) + tuple(v.shape))
 
 
 def zigzag_ring_flash_attn_forward(
@@ -51,6 +81,23 @@ def zigzag_ring_flash_attn_forward(
 
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+
+    if _exchange_mode() == "gather":
+        gather, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
+               out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
+        gather.wait()
+        for step in range(1, comm.world_size):
+            src = (comm.rank - step) % comm.world_size
+            ks, vs = k_all[src], v_all[src]
+            if step <= comm.rank:
+                be.fwd(q, ks[:, :half], vs[:, :half], softmax_scale=softmax_scale, causal=False,
+                       out_acc=out_acc, lse_acc=lse_acc)
+            else:
+                be.fwd(q[:, half:], ks, vs, softmax_scale=softmax_scale, causal=False,
+                       out_acc=out_acc[:, half:], lse_acc=lse_acc[:, :, half:])
+        return be.cast(out_acc, q.dtype), lse_acc
+
     next_k, next_v = None, None
 
     for step in range(comm.world_size):
@@ -112,6 +159,36 @@ def zigzag_ring_flash_attn_backward(
         return dq, dk, dv
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
+
+    if _exchange_mode() == "gather":
+        W, rank = kv_comm.world_size, kv_comm.rank
+        gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+        # per-chunk fp32 contributions of THIS rank's queries; chunk c is summed over ranks by the
+        # reduce-scatter.  Zero-filled: a "front" step only produces the first half of its chunk.
+        dk_cat = torch.zeros((W * k.shape[0],) + tuple(k.shape[1:]), dtype=torch.float32, device=q.device)
+        dv_cat = torch.zeros((W * v.shape[0],) + tuple(v.shape[1:]), dtype=torch.float32, device=q.device)
+        dk_all, dv_all = dk_cat.view((W,) + tuple(k.shape)), dv_cat.view((W,) + tuple(v.shape))
+        be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
+               dq_acc=dq, dk_acc=dk_all[rank], dv_acc=dv_all[rank], acc_init=True,
+               deterministic=deterministic)                                    # beside the all-gather
+        gather.wait()
+        for step in range(1, W):
+            src = (rank - step) % W
+            ks, vs = k_all[src], v_all[src]
+            if step <= rank:
+                be.bwd(dout, q, ks[:, :half], vs[:, :half], softmax_lse, delta, softmax_scale=softmax_scale,
+                       causal=False, dq_acc=dq, dk_acc=dk_all[src][:, :half], dv_acc=dv_all[src][:, :half],
+                       acc_init=False, deterministic=deterministic)
+            else:
+                be.bwd(dout[:, half:], q[:, half:], ks, vs, softmax_lse[:, :, half:], delta[:, :, half:],
+                       softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:],
+                       dk_acc=dk_all[src], dv_acc=dv_all[src], acc_init=False, deterministic=deterministic)
+        dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
+        dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
+        reduce_scatter(dk, dk_cat, group=process_group)
+        reduce_scatter(dv, dv_cat, group=process_group)
+        return be.cast(dq, q.dtype), be.cast(dk, q.dtype), be.cast(dv, q.dtype)
+
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
     dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
     next_dk, next_dv = None, None

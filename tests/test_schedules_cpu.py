@@ -22,6 +22,17 @@ def test_schedules_match_reference_golden(W):
     assert not errs, "\n".join(errs)
 
 
+@pytest.mark.parametrize("W", [2, 4])
+def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
+    """RFA_ZIGZAG_EXCHANGE=ring (the reference's hop-by-hop protocol; the default is the mesh-aware
+    all-gather / reduce-scatter form exercised by the test above) gives the same golden results."""
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "ring")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
+    assert names
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
 def test_unmodified_reference_runs_on_the_flash_attn_shim():
     """INTEGRATION.md route B: the reference's own schedule code (loaded unmodified from /root/reference)
     on top of the shipped `flash_attn` compatibility package reproduces the golden vectors.  Build
