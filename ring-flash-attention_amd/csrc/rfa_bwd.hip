@@ -432,20 +432,25 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     voff_q[i] = (row * (int)p.q_st.row + chunk * 8) * 2;
     voff_do[i] = (row * (int)p.dout_st.row + chunk * 8) * 2;
   }
-  // The workgroup streams the Q/dO tiles jt0 .. jt1-1 of ALL G query heads of its K/V head, one head after
-  // the other, through the same two LDS stages (no drain between heads): dK/dV of the group are summed in
-  // the fp32 accumulators and written once — no per-head partials, no group-reduction pass.
+  // The workgroup streams the Q/dO tiles jt0 .. jt1-1 of ALL G query heads of its K/V head through the
+  // same two LDS stages: dK/dV of the group are summed in the fp32 accumulators and written once — no
+  // per-head partials, no group-reduction pass.
   int dma_stage = 0;                                  // LDS stage the next load_tile() fills (scalar)
-  int ld_g = 0, ld_j = jt0;                           // (head in group, tile) the next load_tile() fetches
+  // Walk order: tiles from the LAST one down to jt0, and for every tile the G heads of the group.  Every
+  // workgroup of a launch, whatever its causal start, then reads the same (tile, head) at about the same
+  // time, so the (kv head = XCD) L2 serves a tile to all co-resident key blocks.  (Walking upward from
+  // jt0, head after head, spreads them over the whole sequence and every tile is re-fetched from HBM per
+  // workgroup: 3.5x the fabric traffic, measured.)
+  int ld_g = 0, ld_j = jt1 - 1;                       // (head in group, tile) the next load_tile() fetches
   auto load_tile = [&]() {
     const int j = ld_j;
     const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
     const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
     const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
     const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
-    if (++ld_j >= jt1) {
-      ld_j = jt0;
-      ++ld_g;
+    if (++ld_g >= G) {
+      ld_g = 0;
+      --ld_j;
     }
     int rows = lq - j * kKvQ;
     rows = rows < kKvQ ? rows : kKvQ;
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   if (par == 0) __builtin_amdgcn_s_setprio(2);
 #endif
   const int ntile = jt1 > jt0 ? (jt1 - jt0) * G : 0;
-  int j = jt0;
+  int j = jt1 - 1, cg = 0;
   for (int f = 0; f < ntile; ++f) {
     if (f + 1 < ntile) load_tile();
     const int qs0 = j * kKvQ + 32 * t;
@@ -622,7 +627,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       }
     }
     if (f + 1 < ntile) write_tile();
-    if (++j >= jt1) j = jt0;
+    if (++cg >= G) {
+      cg = 0;
+      --j;
+    }
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
     tq[0] ^= kKvTileBytes;
     tq[1] ^= kKvTileBytes;
