@@ -132,8 +132,9 @@ typedef struct {
   rfa_strides dq_acc_st, dk_acc_st, dv_acc_st;
   int32_t acc_init;
   /* workspace for dK/dV partials (already summed over the query heads of a K/V group), io dtype,
-   * 2 * total_k*Hk*D elements (rfa_bwd_workspace_bytes).  May be NULL iff dk_acc == NULL and
-   * phases == 0. */
+   * 2 * total_k*Hk*D elements (rfa_bwd_workspace_bytes).  May be NULL whenever
+   * rfa_bwd_workspace_bytes() returns 0: single-phase calls that write dk/dv, or that overwrite
+   * dk_acc/dv_acc (acc_init or RFA_BWD_KV_OVERWRITE). */
   void *workspace;
   const int32_t *cu_seqlens_q, *cu_seqlens_k;
   int32_t q_half, k_half;
@@ -157,7 +158,12 @@ enum {
   RFA_BWD_REDUCE = 2,
   /* measurement aids, valid together with RFA_BWD_COMPUTE: launch only one of the two kernels */
   RFA_BWD_SKIP_DKDV = 4,
-  RFA_BWD_SKIP_DQ = 8
+  RFA_BWD_SKIP_DQ = 8,
+  /* dk_acc / dv_acc are OVERWRITTEN with this block's dK/dV (fp32) while dq_acc still follows
+   * acc_init — for schedules in which every dK/dV accumulator slot receives exactly one block
+   * (all-gather / reduce-scatter exchange).  In a single-phase call the dK/dV kernel then stores
+   * fp32 straight into dk_acc / dv_acc: no workspace, no reduction pass. */
+  RFA_BWD_KV_OVERWRITE = 16
 };
 
 typedef struct {

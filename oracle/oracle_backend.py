@@ -92,6 +92,8 @@ class OracleBackend:
             dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None, acc_init=False,
             deterministic=False, phases=BWD_ALL):
         pairs = list(zip(_seqs(q, cu_seqlens_q, q_half), _seqs(k, cu_seqlens_k, k_half)))
+        kv_init = acc_init or bool(phases & 16)          # RFA_BWD_KV_OVERWRITE (include/rfa.h)
+        phases &= 3
         if phases in (BWD_ALL, BWD_COMPUTE):
             pend = []
             for (bq, qs, ql), (bk, ks, kl) in pairs:
@@ -110,8 +112,8 @@ class OracleBackend:
             for ((bq, qs, ql), (bk, ks, kl)), (gk, gv) in zip(pairs, self._pending):
                 if dk_acc is not None:
                     tk, tv = _rows(dk_acc, bk, ks, kl), _rows(dv_acc, bk, ks, kl)
-                    tk.copy_(gk.float() if acc_init else tk + gk.float())
-                    tv.copy_(gv.float() if acc_init else tv + gv.float())
+                    tk.copy_(gk.float() if kv_init else tk + gk.float())
+                    tv.copy_(gv.float() if kv_init else tv + gv.float())
                 else:
                     _rows(dk, bk, ks, kl).copy_(gk)
                     _rows(dv, bk, ks, kl).copy_(gv)

@@ -108,8 +108,16 @@ int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {
 // (bf16/fp16 partials, (rows, Hk, D) x 2) is only used when the result is ADDED to fp32 accumulators or
 // when compute and reduction are issued as two phases (ring steps: compute overlaps the arrival of the
 // accumulators).
+static bool bwd_single_phase(const rfa_bwd_args* a) {
+  return (a->phases & (RFA_BWD_COMPUTE | RFA_BWD_REDUCE)) == 0;
+}
+// single-phase call whose dK/dV accumulators are overwritten: the kernel stores fp32 directly
+static bool bwd_kv_direct(const rfa_bwd_args* a) {
+  return a->dk_acc != nullptr && bwd_single_phase(a) && (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE));
+}
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
-  return a->dk_acc != nullptr || a->phases != RFA_BWD_ALL;
+  if (!bwd_single_phase(a)) return true;
+  return a->dk_acc != nullptr && !bwd_kv_direct(a);
 }
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
@@ -159,7 +167,11 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block() - 1) / bwd_dkdv_keys_per_block();
 
   Strides ws_st{};
-  if (ws) {
+  if (bwd_kv_direct(a)) {
+    p.dk = a->dk_acc; p.dv = a->dv_acc;
+    p.dk_st = cv(a->dk_acc_st); p.dv_st = cv(a->dv_acc_st);
+    p.kv_f32 = 1;
+  } else if (ws) {
     // partials: (rows, Hk, D) contiguous; dense rows = b*Sk + row (own batch stride)
     ws_st.head = a->D;
     ws_st.row = (int64_t)a->Hk * a->D;
@@ -171,8 +183,9 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
   }
-  const bool do_compute = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_COMPUTE);
-  const bool do_reduce = a->phases == RFA_BWD_ALL || (a->phases & RFA_BWD_REDUCE);
+  const bool do_compute = bwd_single_phase(a) || (a->phases & RFA_BWD_COMPUTE);
+  const bool do_reduce = bwd_single_phase(a) || (a->phases & RFA_BWD_REDUCE);
+  const int kv_init = (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE)) ? 1 : 0;
   if (do_compute) {
     if (!(a->phases & RFA_BWD_SKIP_DQ) && launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
     if (!(a->phases & RFA_BWD_SKIP_DKDV) && launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
@@ -184,7 +197,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       r.src_st = ws_st;
       r.cu_k = a->cu_seqlens_k;
       r.B = a->B; r.Hk = a->Hk; r.G = 1; r.D = a->D; r.Sk = a->Sk;   // groups are already summed
-      r.k_half = a->k_half; r.acc_init = a->acc_init ? 1 : 0;
+      r.k_half = a->k_half; r.acc_init = kv_init;
       if (a->dk_acc) {
         r.dst_acc = which ? a->dv_acc : a->dk_acc;
         r.dst_acc_st = cv(which ? a->dv_acc_st : a->dk_acc_st);

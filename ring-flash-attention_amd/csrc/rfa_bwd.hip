@@ -663,6 +663,29 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 
   if (krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
+  if (p.kv_f32) {
+    // fp32 store straight into the caller's accumulator slot (overwrite): lane (key, g) holds, per
+    // (dblk, jj), the 4 consecutive columns 32 dblk + 8 jj + 4 g .. +3
+    const f32x16(&fin)[4] = (par == 0) ? dk : dv;
+    const float sc_ = (par == 0) ? p.scale : 1.f;
+    const int64_t sb = (par == 0) ? p.dk_st.batch : p.dv_st.batch;
+    const int64_t sr_ = (par == 0) ? p.dk_st.row : p.dv_st.row;
+    const int64_t sh = (par == 0) ? p.dk_st.head : p.dv_st.head;
+    float* ob = (float*)((par == 0) ? p.dk : p.dv) + kbatch * sb + orow * sr_ + (int64_t)hk * sh;
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (kFullD || d0 < p.D) {
+          f32x4 x;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+          *(f32x4*)(ob + d0) = x;
+        }
+      }
+    return;
+  }
   if (par == 0) {
     T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)hk * p.dk_st.head;
     store_rows16<T, kFullD>(dkb, dk, p.scale, g, p.D, true);

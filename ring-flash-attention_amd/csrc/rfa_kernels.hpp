@@ -43,6 +43,7 @@ struct BwdParams {
   int B, H, Hk, D, Sq, Sk;
   int q_half, k_half;
   int causal, acc_init;
+  int kv_f32;          // dk / dv point to fp32 buffers (overwritten), strides in fp32 elements
   int nqblk, nkblk;
   float scale;
 };

@@ -14,6 +14,7 @@ RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
 BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
+BWD_KV_OVERWRITE = 16     # dk_acc / dv_acc are overwritten (dq_acc still follows acc_init)
 
 
 class Strides(C.Structure):

@@ -164,7 +164,8 @@ def zigzag_ring_flash_attn_backward(
         W, rank = kv_comm.world_size, kv_comm.rank
         gather, k_all, v_all = _gather_kv(process_group, k, v, W)
         # per-chunk fp32 contributions of THIS rank's queries; chunk c is summed over ranks by the
-        # reduce-scatter.  Zero-filled: a "front" step only produces the first half of its chunk.
+        # reduce-scatter.  Zero-filled: a "front" step only produces the first half of its chunk.  Every
+        # slot is written exactly once (BWD_KV_OVERWRITE): the dK/dV kernel stores fp32 straight into it.
         dk_cat = torch.zeros((W * k.shape[0],) + tuple(k.shape[1:]), dtype=torch.float32, device=q.device)
         dv_cat = torch.zeros((W * v.shape[0],) + tuple(v.shape[1:]), dtype=torch.float32, device=q.device)
         dk_all, dv_all = dk_cat.view((W,) + tuple(k.shape)), dv_cat.view((W,) + tuple(v.shape))
@@ -178,11 +179,12 @@ def zigzag_ring_flash_attn_backward(
             if step <= rank:
                 be.bwd(dout, q, ks[:, :half], vs[:, :half], softmax_lse, delta, softmax_scale=softmax_scale,
                        causal=False, dq_acc=dq, dk_acc=dk_all[src][:, :half], dv_acc=dv_all[src][:, :half],
-                       acc_init=False, deterministic=deterministic)
+                       acc_init=False, deterministic=deterministic, phases=_C.BWD_KV_OVERWRITE)
             else:
                 be.bwd(dout[:, half:], q[:, half:], ks, vs, softmax_lse[:, :, half:], delta[:, :, half:],
                        softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:],
-                       dk_acc=dk_all[src], dv_acc=dv_all[src], acc_init=False, deterministic=deterministic)
+                       dk_acc=dk_all[src], dv_acc=dv_all[src], acc_init=False, deterministic=deterministic,
+                       phases=_C.BWD_KV_OVERWRITE)
         dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
         dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
         reduce_scatter(dk, dk_cat, group=process_group)

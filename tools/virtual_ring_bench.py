@@ -3,7 +3,8 @@
 sequence of zigzag_ring_flash_attn_{forward,backward} (fused merge epilogues, fp32 accumulators,
 two-phase backward) with the ring exchange replaced by pre-filled local buffers.  Compared with
 W x the world-size-1 time, it isolates what the multi-step form costs before any xGMI traffic.
-usage: python tools/virtual_ring_bench.py [W] [rank] [kv_heads]"""
+usage: python tools/virtual_ring_bench.py [W] [rank] [kv_heads] [ring|gather]   (default: gather = the
+default exchange of the dense zigzag path: single-phase backward into per-chunk fp32 slots)"""
 import os
 import sys
 import time
@@ -17,6 +18,7 @@ from ring_flash_attn.backend import get_backend
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 RANK = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 HK = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+MODE = sys.argv[4] if len(sys.argv) > 4 else "gather"
 S, H, D = 8192, 32, 128
 dev = torch.device("cuda:0")
 be = get_backend()
@@ -43,7 +45,29 @@ def fwd():
     return be.cast(out_acc, torch.bfloat16), lse_acc
 
 
+def bwd_gather(out, lse):
+    delta = torch.empty((1, H, S), dtype=torch.float32, device=dev)
+    be.bwd_preprocess(dout, out, delta)
+    dq = torch.empty((1, S, H, D), dtype=torch.float32, device=dev)
+    dk_all = torch.zeros((W, 1, S, HK, D), dtype=torch.float32, device=dev)
+    dv_all = torch.zeros_like(dk_all)
+    for step in range(W):
+        k, v = ks[step], vs[step]
+        if step == 0:
+            be.bwd(dout, q, k, v, lse, delta, softmax_scale=scale, causal=True, dq_acc=dq, dk_acc=dk_all[0], dv_acc=dv_all[0], acc_init=True)
+        elif step <= RANK:
+            be.bwd(dout, q, k[:, :half], v[:, :half], lse, delta, softmax_scale=scale, causal=False, dq_acc=dq,
+                   dk_acc=dk_all[step][:, :half], dv_acc=dv_all[step][:, :half], phases=_C.BWD_KV_OVERWRITE)
+        else:
+            be.bwd(dout[:, half:], q[:, half:], k, v, lse[:, :, half:], delta[:, :, half:], softmax_scale=scale, causal=False,
+                   dq_acc=dq[:, half:], dk_acc=dk_all[step], dv_acc=dv_all[step], phases=_C.BWD_KV_OVERWRITE)
+    # (the reduce-scatter would run here; its local part is one pass over dk_all / dv_all)
+    return be.cast(dq, torch.bfloat16), be.cast(dk_all[0], torch.bfloat16), be.cast(dv_all[0], torch.bfloat16)
+
+
 def bwd(out, lse):
+    if MODE == "gather":
+        return bwd_gather(out, lse)
     delta = torch.empty((1, H, S), dtype=torch.float32, device=dev)
     be.bwd_preprocess(dout, out, delta)
     dq = torch.empty((1, S, H, D), dtype=torch.float32, device=dev)
@@ -84,6 +108,6 @@ t1f, _ = timeit(lambda: be.fwd(q, ks[0], vs[0], softmax_scale=scale, causal=True
 d1 = torch.empty_like(l1); be.bwd_preprocess(dout, o1, d1)
 g = [torch.empty_like(q), torch.empty_like(ks[0]), torch.empty_like(vs[0])]
 t1b, _ = timeit(lambda: be.bwd(dout, q, ks[0], vs[0], l1, d1, softmax_scale=scale, causal=True, dq=g[0], dk=g[1], dv=g[2]), 20)
-print(f"W={W} rank={RANK} Hk={HK}: fwd {tf:.3f} ms (= {tf / W:.3f}/step, W=1 kernel {t1f:.3f})  "
+print(f"W={W} rank={RANK} Hk={HK} {MODE}: fwd {tf:.3f} ms (= {tf / W:.3f}/step, W=1 kernel {t1f:.3f})  "
       f"bwd {tb:.3f} ms (= {tb / W:.3f}/step, W=1 {t1b:.3f})  fwd+bwd {tf + tb:.2f} ms -> {1e3 / (tf + tb):.1f} it/s compute-only; "
       f"ideal {1e3 / (W * (t1f + t1b)):.1f} it/s; efficiency {(W * (t1f + t1b)) / (tf + tb):.3f}")
