@@ -124,3 +124,34 @@ def test_public_functions_autograd(built):
         FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p=0.1)
     with pytest.raises(NotImplementedError):
         FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], window_size=(128, 0), causal=True)
+
+
+@pytest.mark.parametrize("D", [128, 96])
+def test_fp16_kernels_match_oracle(built, D):
+    """The fp16 instances of every attention kernel (the reference accepts fp16 as well as bf16): D = 128
+    takes the LDS-DMA path, D = 96 the zero-padded register path."""
+    from flash_attn import flash_attn_interface as F
+    from oracle import flash_attn_ref as O
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    B, Sq, Sk, H, Hk = 1, 330, 330, 4, 2
+    H16 = torch.float16
+    q = torch.randn(B, Sq, H, D, generator=g).to(H16)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(H16)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(H16)
+    do = torch.randn(B, Sq, H, D, generator=g).to(H16)
+    scale = D ** -0.5
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, True)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, True)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out, lse, _, _ = F._flash_attn_forward(qd, kd, vd, 0.0, scale, True)
+    assert out.dtype == H16
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    F._flash_attn_backward(dod, qd, kd, vd, out, lse, dq, dk, dv, 0.0, scale, True)
+    # fp16 has 3 more mantissa bits than bf16: tighter than the bf16 tolerances
+    _check("out", out, ro, 4e-3)
+    _check("lse", lse, rl, 1e-3)
+    for n, a, b in (("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv)):
+        _check(n, a, b, 3e-3, 5e-3)
