@@ -29,6 +29,7 @@ DT = torch.bfloat16
 CASES = {
     "zigzag_dense_w4_gqa": dict(kind="zigzag", W=4, B=1, S=128, H=4, Hk=2, D=32, seed=11),
     "zigzag_dense_w2_mha_d128": dict(kind="zigzag", W=2, B=1, S=32, H=2, Hk=2, D=128, seed=12),
+    "zigzag_dense_w8_gqa": dict(kind="zigzag", W=8, B=1, S=32, H=4, Hk=2, D=32, seed=23),   # the driver's largest N
     "ring_dense_w4_causal": dict(kind="ring", W=4, B=2, S=64, H=2, Hk=2, D=32, causal=True, seed=13),
     "ring_dense_w2_noncausal_gqa": dict(kind="ring", W=2, B=1, S=64, H=4, Hk=1, D=64, causal=False, seed=14),
     "zigzag_varlen_w2": dict(kind="zigzag_varlen", W=2, cu=[0, 16, 80, 128], H=2, Hk=2, D=32, seed=15),

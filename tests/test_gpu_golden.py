@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 
 
-@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("W", [2, 4, 8])
 def test_multirank_hip_matches_reference_golden(W):
     import _ring_worker as RW
     import make_golden as MG

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as MG
 
 
-@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("W", [2, 4, 8])
 def test_schedules_match_reference_golden(W):
     names = [n for n, c in MG.CASES.items() if c["W"] == W]
     assert names
@@ -22,7 +22,7 @@ def test_schedules_match_reference_golden(W):
     assert not errs, "\n".join(errs)
 
 
-@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("W", [2, 4, 8])
 def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
     """RFA_ZIGZAG_EXCHANGE=ring (the reference's hop-by-hop protocol; the default is the mesh-aware
     all-gather / reduce-scatter form exercised by the test above) gives the same golden results."""
