@@ -4,9 +4,11 @@ Mirrors the public surface of /root/reference/ring_flash_attn/utils.py (`RingCom
 `AllGatherComm`, `update_out_and_lse`, `flatten_varlen_lse`, `unflatten_varlen_lse`) with the
 same method names and error behaviour, re-designed for RCCL over xGMI:
 
-* `RingComm` posts ONE batched isend/irecv group per ring step (RCCL fuses it into one
-  kernel on its own internal stream, so the transfer runs beside the attention kernel on the
-  compute stream); `wait()` only makes the compute stream wait on that event — no host sync.
+* `RingComm` posts ONE batched isend/irecv group per ring step under an explicit side HIP stream
+  (`comm_stream`): the transfer is ordered after the compute stream at commit (send data ready,
+  receive buffer free) and runs beside the attention kernel; `wait()` makes the compute stream
+  wait for exactly that transfer — no host sync.  Collectives (`AllGatherComm`,
+  `reduce_scatter_async`, `all_to_all_async`) are posted the same way.
 * receive buffers are recycled across steps (two alternating sets) instead of a fresh
   `torch.empty_like` per step (reference utils.py:117).
 * `update_out_and_lse` is one HIP kernel (csrc/rfa_aux.hip: merge_kernel) instead of ~6
@@ -65,6 +67,54 @@ def _needs_host_staging(process_group, t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend(process_group) == "gloo"
 
 
+# ---------------------------------------------------------------------------------------------
+# Side HIP stream for the exchange.  torch's RCCL process group orders a collective after the
+# *current* stream at the moment it is posted and makes the *current* stream wait in Work.wait();
+# by posting and waiting under an explicit per-device side stream, the dependencies between the
+# attention kernels (compute stream) and the transfers are explicit:
+#     commit():  side waits for `ready` (the compute stream up to here: the send data exists and the
+#                receive buffer's last reader has been enqueued) -> the transfer is posted under `side`
+#     wait():    side waits for the transfer; the compute stream then waits for the side stream
+# so the compute stream never blocks on anything but the one transfer it is about to consume, and
+# transfers posted later (the next step's) are not serialised behind this wait.
+_SIDE_STREAMS = {}
+
+
+def comm_stream(device: torch.device) -> "torch.cuda.Stream":
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = torch.cuda.Stream(device=torch.device("cuda", idx))
+        _SIDE_STREAMS[idx] = st
+    return st
+
+
+def _use_side_stream(process_group, t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend(process_group) != "gloo"
+
+
+# ---------------------------------------------------------------------------------------------
+# MEASUREMENT HOOK (bench.py `comm.exposed_ms`, tools/virtual_ring_bench.py): with a loopback
+# (rank, world) installed, RingComm / AllGatherComm / the dK/dV exchanges move data between LOCAL
+# buffers only, so ONE process executes the exact kernel sequence of rank `rank` of a `world`-rank
+# job with no communication — "measured step minus loopback step" is the exposed exchange time.
+# The results are meaningless (every peer's K/V is a copy of the local one); nothing in the package
+# installs it.
+_LOOPBACK = None
+
+
+def set_loopback(rank_world=None):
+    global _LOOPBACK
+    _LOOPBACK = rank_world
+
+
+def group_rank_world(process_group):
+    """(rank, world_size) of the group — the one place the schedules ask for it"""
+    if _LOOPBACK is not None:
+        return _LOOPBACK
+    return dist.get_rank(process_group), dist.get_world_size(process_group)
+
+
 class RingComm:
     """Neighbour exchange on a ring of the process group: send to rank+1, receive from rank-1.
 
@@ -77,25 +127,27 @@ class RingComm:
     def __init__(self, process_group: dist.ProcessGroup):
         self._process_group = process_group
         self._ops = []
-        self.rank = dist.get_rank(self._process_group)
-        self.world_size = dist.get_world_size(self._process_group)
+        self.rank, self.world_size = group_rank_world(process_group)
         self._reqs = None
         self._staged = []          # (host_recv, device_recv) pairs for the gloo staging path
-        self._pool = {}            # recycled receive buffers, keyed by (shape, dtype, device)
+        self._local = []           # (src, dst) pairs of the loopback measurement hook
+        self._pool = {}            # recycled receive buffers, keyed by (slot, shape, dtype, device)
+        self._side = None          # side stream the pending transfer was posted under (RCCL path)
 
         self.send_rank = (self.rank + 1) % self.world_size
         self.recv_rank = (self.rank - 1) % self.world_size
 
-        if process_group is not None:
+        if process_group is not None and _LOOPBACK is None:
             self.send_rank = dist.get_global_rank(self._process_group, self.send_rank)
             self.recv_rank = dist.get_global_rank(self._process_group, self.recv_rank)
 
     def _recv_buffer(self, like: torch.Tensor) -> torch.Tensor:
         """Recycled receive buffer.  Per (position in the batch, shape, dtype) there are two
         buffers used alternately: the one handed out at step s was the *send* source of step
-        s-1, whose transfer and whose readers were all enqueued before this step's commit
-        (RCCL orders its stream after the compute stream at commit), so it is free again."""
-        slot = len(self._ops) // 2
+        s-1, whose transfer has been waited for and whose readers were all enqueued on the compute
+        stream before this step's commit (which orders the transfer after that stream), so it is
+        free again."""
+        slot = len(self._ops) // 2 + len(self._local)
         key = (slot, tuple(like.shape), like.dtype, like.device)
         pair = self._pool.get(key)
         if pair is None:
@@ -113,6 +165,9 @@ class RingComm:
             res = self._recv_buffer(to_send)
         else:
             res = recv_tensor
+        if _LOOPBACK is not None:
+            self._local.append((to_send, res))
+            return res
         if _needs_host_staging(self._process_group, to_send):
             host_send = to_send.detach().to("cpu")
             host_recv = torch.empty(res.shape, dtype=res.dtype, device="cpu")
@@ -131,16 +186,38 @@ class RingComm:
     def commit(self):
         if self._reqs is not None:
             raise RuntimeError("commit called twice")
-        self._reqs = dist.batch_isend_irecv(self._ops)
+        if _LOOPBACK is not None:
+            for src, dst in self._local:
+                dst.copy_(src)
+            self._reqs = []
+            return
+        t = self._ops[0].tensor if self._ops else None
+        if t is not None and _use_side_stream(self._process_group, t):
+            side = comm_stream(t.device)
+            side.wait_stream(torch.cuda.current_stream(t.device))     # `ready`
+            with torch.cuda.stream(side):
+                self._reqs = dist.batch_isend_irecv(self._ops)
+            self._side = side
+        else:
+            self._reqs = dist.batch_isend_irecv(self._ops)
 
     def wait(self):
         if self._reqs is None:
             raise RuntimeError("wait called before commit")
-        for req in self._reqs:
-            req.wait()
+        if self._side is not None:
+            side = self._side
+            with torch.cuda.stream(side):
+                for req in self._reqs:
+                    req.wait()                                         # the side stream waits for the transfer
+            torch.cuda.current_stream(side.device).wait_stream(side)   # `done`
+            self._side = None
+        else:
+            for req in self._reqs:
+                req.wait()
         for host_recv, dev in self._staged:
             dev.copy_(host_recv)
         self._staged = []
+        self._local = []
         self._reqs = None
         self._ops = []
 
@@ -156,42 +233,94 @@ class RingComm:
         return next_k, next_v
 
 
+class _Work:
+    """a posted collective: wait() makes the compute (current) stream wait for it"""
+
+    def __init__(self, handle, side=None, after=None):
+        self.handle, self.side, self.after = handle, side, after
+
+    def wait(self):
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                self.handle.wait()
+            torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+        elif self.handle is not None:
+            self.handle.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
+def _post(process_group, t: torch.Tensor, fn) -> _Work:
+    """fn() posts an async collective and returns its Work; under the side stream when the group is RCCL and
+    the data lives on the device"""
+    if _use_side_stream(process_group, t):
+        side = comm_stream(t.device)
+        side.wait_stream(torch.cuda.current_stream(t.device))
+        with torch.cuda.stream(side):
+            return _Work(fn(), side)
+    return _Work(fn())
+
+
 class AllGatherComm:
     """Async all-gather handles (reference utils.py:154-168)."""
 
     def __init__(self, group=None) -> None:
         self.group = group
         self.handles = []
-        self._staged = []
 
     def all_gather(self, output_tensor: torch.Tensor, input_tensor: torch.Tensor):
+        if _LOOPBACK is not None:
+            world = _LOOPBACK[1]
+            output_tensor.view(world, -1).copy_(input_tensor.reshape(1, -1).expand(world, -1))
+            return
         if _needs_host_staging(self.group, input_tensor):
             host_in = input_tensor.detach().to("cpu").contiguous()
             host_out = torch.empty(output_tensor.shape, dtype=output_tensor.dtype, device="cpu")
             handle = dist.all_gather_into_tensor(host_out, host_in, group=self.group, async_op=True)
-            self._staged.append((host_out, output_tensor))
+            self.handles.append(_Work(handle, after=lambda: output_tensor.copy_(host_out)))
         else:
-            handle = dist.all_gather_into_tensor(output_tensor, input_tensor, group=self.group, async_op=True)
-        self.handles.append(handle)
+            self.handles.append(_post(self.group, input_tensor, lambda: dist.all_gather_into_tensor(
+                output_tensor, input_tensor, group=self.group, async_op=True)))
 
     def wait(self):
         for handle in self.handles:
             handle.wait()
-        for host_out, dev in self._staged:
-            dev.copy_(host_out)
-        self._staged = []
         self.handles = []
 
 
+def _sum_on_host(output, input_, group) -> _Work:
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    host = input_.detach().to("cpu", torch.float32)
+    handle = dist.all_reduce(host, group=group, async_op=True)
+    return _Work(handle, after=lambda: output.copy_(host.chunk(world, dim=0)[rank].reshape(output.shape).to(output.dtype)))
+
+
+def reduce_scatter_async(output: torch.Tensor, input_: torch.Tensor, group=None) -> _Work:
+    """output = this rank's dim-0 chunk of the sum over ranks of input_; the returned handle's wait() makes the
+    compute stream wait for it.  gloo (tests: device memory shared by several ranks, or 16-bit CPU tensors,
+    which gloo would add in their own precision): fp32 all_reduce on the host."""
+    if _LOOPBACK is not None:
+        rank, world = _LOOPBACK
+        output.copy_(input_.chunk(world, dim=0)[rank].reshape(output.shape))
+        return _Work(None)
+    if dist.get_backend(group) == "gloo" and (input_.is_cuda or input_.dtype not in (torch.float32, torch.float64)):
+        return _sum_on_host(output, input_, group)
+    return _post(group, input_, lambda: dist.reduce_scatter_tensor(output, input_, group=group, async_op=True))
+
+
 def reduce_scatter(output: torch.Tensor, input_: torch.Tensor, group=None):
-    """dist.reduce_scatter_tensor with the same gloo host-staging escape hatch (gloo has no
-    reduce_scatter_tensor for device memory; emulate with all_reduce on the host)."""
-    if dist.get_backend(group) == "gloo":
-        world = dist.get_world_size(group)
-        rank = dist.get_rank(group)
-        host = input_.detach().to("cpu", torch.float32)
-        dist.all_reduce(host, group=group)
-        chunk = host.chunk(world, dim=0)[rank]
-        output.copy_(chunk.to(output.dtype))
-    else:
-        dist.reduce_scatter_tensor(output, input_, group=group)
+    reduce_scatter_async(output, input_, group).wait()
+
+
+def all_to_all_async(output: torch.Tensor, input_: torch.Tensor, group=None) -> _Work:
+    """dim-0 chunk j of input_ goes to rank j; dim-0 chunk i of output comes from rank i"""
+    if _LOOPBACK is not None:
+        output.copy_(input_)
+        return _Work(None)
+    if _needs_host_staging(group, input_):
+        host_in = input_.detach().to("cpu").contiguous()
+        host_out = torch.empty(output.shape, dtype=output.dtype, device="cpu")
+        handle = dist.all_to_all_single(host_out, host_in, group=group, async_op=True)
+        return _Work(handle, after=lambda: output.copy_(host_out))
+    return _post(group, input_, lambda: dist.all_to_all_single(output, input_, group=group, async_op=True))

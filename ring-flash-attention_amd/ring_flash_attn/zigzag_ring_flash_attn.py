@@ -16,16 +16,29 @@ MI355X-first differences:
     dK/dV partials are group-summed straight into the travelling fp32 accumulators, split in
     two phases so the kernels overlap the arrival of those accumulators;
   * world_size == 1 short-circuits to a single kernel writing q.dtype directly;
-  * K/V exchange is mesh-aware by default (RFA_ZIGZAG_EXCHANGE=gather): ONE all-gather of K and V,
-    overlapped with the local causal block, replaces the W-1 neighbour hops of the forward, and in
-    the backward one all-gather + one fp32 reduce-scatter of the per-chunk dK/dV contributions
-    replace 2(W-1)+W hops.  A neighbour ring drives 1 of a rank's 7 xGMI links and sits on the
-    critical path once per step (33.5 MB bf16 K/V per step against a 0.5 ms attention step at the
-    headline shape; 100 MB incl. fp32 dK/dV in the backward); the collectives use the
-    whole mesh and put one transfer, not W, on the critical path.  The per-step kernels, their
-    arguments and the merge order are exactly those of the ring form (the forward is bit-identical;
-    dK/dV differ by fp32 summation order only).  RFA_ZIGZAG_EXCHANGE=ring restores the reference's
-    hop-by-hop protocol (same results, kept for networks where a ring is the better map).
+  * two exchange forms (RFA_ZIGZAG_EXCHANGE = auto | gather | ring, default auto):
+      ring    the reference's hop-by-hop protocol: per step one batched isend/irecv of K/V (and of the
+              travelling fp32 dK/dV accumulators in the backward) to / from the ring neighbours, posted under
+              the side stream before the step's kernels and waited after them.  O(S/W) memory per rank.
+      gather  mesh-aware: ONE all-gather of K and V (overlapped with the local causal block) replaces the
+              W-1 neighbour hops of the forward; in the backward one all-gather plus ONE exchange of the
+              per-chunk dK/dV contributions (every rank returns chunk c's contribution to its owner c, the
+              owner sums the W arrivals in fp32) replace 2(W-1)+W hops.  A neighbour ring drives 1 of a
+              rank's 7 xGMI links and puts a transfer on the critical path of every step (33.5 MB bf16 K/V
+              against a 0.5 ms forward step at the headline shape, 100 MB incl. fp32 dK/dV in the
+              backward); the collectives use the whole mesh and put one transfer, not W, on it.
+              Cost: scratch of W x (K,V) in the io dtype plus W x (dK,dV) contributions per rank — O(S_total)
+              instead of O(S_total/W): 0.27 + 0.27 GB at W = 8, Hk = 8, S = 8192/rank (0.54 GB with fp32
+              contributions), 4.3 + 4.3 GB at 128K tokens/rank.
+      auto    gather while that scratch stays below RFA_GATHER_MAX_BYTES (default 4 GiB), ring beyond —
+              long contexts keep ring attention's memory scaling.  The choice depends on shapes only, so
+              every rank takes the same one.
+    The per-step kernels, their arguments and the merge order are the same in both forms (the forward is
+    bit-identical; dK/dV differ by summation order / rounding point only).
+  * dK/dV contributions of the gather form travel in the io dtype by default (RFA_DKV_WIRE = io | fp32):
+    every block's dK/dV is rounded to bf16 once and summed in fp32 at the owner — exactly the rounding
+    points of the reference, whose flash_attn calls return bf16 block gradients that are then added into
+    fp32 buffers (zigzag_ring_flash_attn.py:137-139,164-187) — at half the xGMI bytes of fp32.
 """
 import os
 
@@ -33,14 +46,29 @@ import torch
 
 from . import _C
 from .backend import get_backend
-from .utils import AllGatherComm, RingComm, reduce_scatter
+from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 
 
-def _exchange_mode() -> str:
-    mode = os.environ.get("RFA_ZIGZAG_EXCHANGE", "gather").lower()
-    if mode not in ("gather", "ring"):
-        raise ValueError(f"RFA_ZIGZAG_EXCHANGE must be 'gather' or 'ring', got {mode!r}")
+def gather_scratch_bytes(k: torch.Tensor, world: int, wire_fp32: bool) -> int:
+    """per-rank scratch of the gather exchange: W x (K, V) io dtype + W x (dK, dV) contributions"""
+    return world * 2 * k.numel() * (k.element_size() + (4 if wire_fp32 else k.element_size()))
+
+
+def _wire_fp32() -> bool:
+    mode = os.environ.get("RFA_DKV_WIRE", "io").lower()
+    if mode not in ("io", "bf16", "fp16", "fp32"):
+        raise ValueError(f"RFA_DKV_WIRE must be 'io' or 'fp32', got {mode!r}")
+    return mode == "fp32"
+
+
+def exchange_mode(k: torch.Tensor, world: int) -> str:
+    mode = os.environ.get("RFA_ZIGZAG_EXCHANGE", "auto").lower()
+    if mode not in ("auto", "gather", "ring"):
+        raise ValueError(f"RFA_ZIGZAG_EXCHANGE must be 'auto', 'gather' or 'ring', got {mode!r}")
+    if mode == "auto":
+        limit = int(os.environ.get("RFA_GATHER_MAX_BYTES", str(4 << 30)))
+        mode = "gather" if gather_scratch_bytes(k, world, _wire_fp32()) <= limit else "ring"
     return mode
 
 
@@ -82,7 +110,7 @@ def zigzag_ring_flash_attn_forward(
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
 
-    if _exchange_mode() == "gather":
+    if exchange_mode(k, comm.world_size) == "gather":
         gather, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
@@ -160,36 +188,60 @@ def zigzag_ring_flash_attn_backward(
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
 
-    if _exchange_mode() == "gather":
+    if exchange_mode(k, kv_comm.world_size) == "gather":
         W, rank = kv_comm.world_size, kv_comm.rank
         gather, k_all, v_all = _gather_kv(process_group, k, v, W)
-        # per-chunk fp32 contributions of THIS rank's queries; chunk c is summed over ranks by the
-        # reduce-scatter.  Zero-filled: a "front" step only produces the first half of its chunk.  Every
-        # slot is written exactly once (BWD_KV_OVERWRITE): the dK/dV kernel stores fp32 straight into it.
-        dk_cat = torch.zeros((W * k.shape[0],) + tuple(k.shape[1:]), dtype=torch.float32, device=q.device)
-        dv_cat = torch.zeros((W * v.shape[0],) + tuple(v.shape[1:]), dtype=torch.float32, device=q.device)
+        # per-chunk contributions of THIS rank's queries: slot c holds this rank's dK/dV for the chunk owned by
+        # rank c.  Every slot is written exactly once (a "front" step produces only the first half of its
+        # chunk: the other half is zero-filled here, r half-chunks instead of the whole buffer), so the dK/dV
+        # kernel stores straight into it: fp32 (BWD_KV_OVERWRITE) or the io dtype — no workspace, no reduction
+        # pass.  The owner then sums the W arrivals of its chunk in fp32.
+        wire32 = _wire_fp32()
+        wdt = torch.float32 if wire32 else q.dtype
+        dk_cat = torch.empty((W * k.shape[0],) + tuple(k.shape[1:]), dtype=wdt, device=q.device)
+        dv_cat = torch.empty((W * v.shape[0],) + tuple(v.shape[1:]), dtype=wdt, device=q.device)
         dk_all, dv_all = dk_cat.view((W,) + tuple(k.shape)), dv_cat.view((W,) + tuple(v.shape))
+
+        def slots(src, rows):
+            if wire32:
+                return dict(dk_acc=dk_all[src][:, rows], dv_acc=dv_all[src][:, rows])
+            return dict(dk=dk_all[src][:, rows], dv=dv_all[src][:, rows])
+
+        full = slice(None)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-               dq_acc=dq, dk_acc=dk_all[rank], dv_acc=dv_all[rank], acc_init=True,
-               deterministic=deterministic)                                    # beside the all-gather
+               dq_acc=dq, acc_init=True, deterministic=deterministic, **slots(rank, full))   # beside the all-gather
         gather.wait()
         for step in range(1, W):
             src = (rank - step) % W
             ks, vs = k_all[src], v_all[src]
             if step <= rank:
+                dk_all[src][:, half:].zero_()
+                dv_all[src][:, half:].zero_()
                 be.bwd(dout, q, ks[:, :half], vs[:, :half], softmax_lse, delta, softmax_scale=softmax_scale,
-                       causal=False, dq_acc=dq, dk_acc=dk_all[src][:, :half], dv_acc=dv_all[src][:, :half],
-                       acc_init=False, deterministic=deterministic, phases=_C.BWD_KV_OVERWRITE)
+                       causal=False, dq_acc=dq, acc_init=False, deterministic=deterministic,
+                       phases=_C.BWD_KV_OVERWRITE, **slots(src, slice(0, half)))
             else:
                 be.bwd(dout[:, half:], q[:, half:], ks, vs, softmax_lse[:, :, half:], delta[:, :, half:],
-                       softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:],
-                       dk_acc=dk_all[src], dv_acc=dv_all[src], acc_init=False, deterministic=deterministic,
-                       phases=_C.BWD_KV_OVERWRITE)
-        dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
-        dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
-        reduce_scatter(dk, dk_cat, group=process_group)
-        reduce_scatter(dv, dv_cat, group=process_group)
-        return be.cast(dq, q.dtype), be.cast(dk, q.dtype), be.cast(dv, q.dtype)
+                       softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:], acc_init=False,
+                       deterministic=deterministic, phases=_C.BWD_KV_OVERWRITE, **slots(src, full))
+        if wire32:
+            dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
+            dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
+            works = [reduce_scatter_async(dk, dk_cat, group=process_group),
+                     reduce_scatter_async(dv, dv_cat, group=process_group)]
+            dq_out = be.cast(dq, q.dtype)                                  # runs beside the exchange
+            for w_ in works:
+                w_.wait()
+            return dq_out, be.cast(dk, q.dtype), be.cast(dv, q.dtype)
+        dk_in, dv_in = torch.empty_like(dk_cat), torch.empty_like(dv_cat)
+        works = [all_to_all_async(dk_in, dk_cat, group=process_group),
+                 all_to_all_async(dv_in, dv_cat, group=process_group)]
+        dq_out = be.cast(dq, q.dtype)                                      # runs beside the exchange
+        for w_ in works:
+            w_.wait()
+        dk = torch.sum(dk_in.view((W,) + tuple(k.shape)), dim=0, dtype=torch.float32).to(q.dtype)
+        dv = torch.sum(dv_in.view((W,) + tuple(v.shape)), dim=0, dtype=torch.float32).to(q.dtype)
+        return dq_out, dk, dv
 
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
     dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)

@@ -12,11 +12,12 @@ CFG = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_atten
            num_key_value_heads=2, head_dim=16, vocab_size=128, max_position_embeddings=256)
 
 
-@pytest.mark.parametrize("stride", [1, 2])
-def test_qwen3_ring_adapter_matches_eager(stride):
-    cu = [0, 23, 70, 96]                       # deliberately not rank aligned
+@pytest.mark.parametrize("W,stride", [(2, 1), (2, 2), (8, 1)])
+def test_qwen3_ring_adapter_matches_eager(W, stride):
+    cu = [0, 23, 70, 96]                       # deliberately not rank aligned (W = 8: 12 tokens per rank,
+    #                                            8 unaligned slices through update_ring_flash_attn_params)
     ref_logits, ref_grads = AW.reference(CFG, cu, torch.float32, torch.device("cpu"))
-    logits, grads = AW.run_world(2, CFG, cu, use_hip=False, heads_k_stride=stride, port=free_port())
+    logits, grads = AW.run_world(W, CFG, cu, use_hip=False, heads_k_stride=stride, port=free_port())
     assert logits.shape == ref_logits.shape
     assert (logits - ref_logits).abs().max() < 2e-4 * max(1.0, ref_logits.abs().max().item())
     for n, g in ref_grads.items():

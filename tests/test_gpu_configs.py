@@ -46,16 +46,30 @@ def _oracle(c, q, k, v, do):
     return out, lse, dq, dk, dv
 
 
-def _run_and_compare(c):
+def _run_and_compare(c, heads=None):
+    """heads: optional list of query heads (MHA only, H == Hk) the CPU oracle is evaluated on — the HIP run
+    always covers every head of the configuration; per-head arithmetic is independent, so a head subset
+    checked over ALL rows bounds the oracle's cost without reducing the size of the GPU problem."""
     import _config_worker as CW
     from conftest import free_port
 
     q, k, v, do = CW.global_inputs(c)
-    ro, rl, rdq, rdk, rdv = _oracle(c, q, k, v, do)
+    if heads is not None:
+        assert c["H"] == c["Hk"]
+        hd = -2
+        sel = torch.tensor(heads)
+        ro, rl, rdq, rdk, rdv = _oracle(c, *[t.index_select(hd, sel) for t in (q, k, v, do)])
+    else:
+        ro, rl, rdq, rdk, rdv = _oracle(c, q, k, v, do)
     with tempfile.TemporaryDirectory() as d:
         res = CW.run_world(c, d, free_port())
     varlen = "cu" in c
     for r, got in enumerate(res):
+        if heads is not None:
+            got = dict(got)
+            for key in ("out", "dq", "dk", "dv"):
+                got[key] = got[key].index_select(-2, sel)
+            got["lse"] = got["lse"].index_select(-2, sel)          # (B,H,S) / (H,T): heads are dim -2 as well
         lo, ldq, ldk, ldv = CW.shard(c, r, [ro, rdq, rdk, rdv])
         if varlen:
             llse = CW.shard(c, r, [rl.transpose(0, 1)])[0].transpose(0, 1)       # (H,T) -> shard rows
@@ -76,7 +90,16 @@ def test_config2_ring_w2_b2_s4096_h16():
 
 
 def test_config4_zigzag_varlen_w8_total32768():
-    _run_and_compare(dict(kind="zigzag_varlen", W=8, cu=[0, 1024, 10240, 32768], H=4, Hk=4, D=128, seed=104))
+    """BASELINE.json configs[3] at its stated shape: world_size 8, 3 packed sequences, 32768 tokens,
+    nheads 32, d 128, bf16 (cu_seqlens of SURVEY §8d).  All 32 heads run through the HIP kernels on every
+    rank; the CPU oracle covers 4 of them (first, last, two in between) over all 32768 rows."""
+    _run_and_compare(dict(kind="zigzag_varlen", W=8, cu=[0, 1024, 10240, 32768], H=32, Hk=32, D=128, seed=104),
+                     heads=[0, 9, 22, 31])
+
+
+def test_config4_zigzag_varlen_w8_gqa_all_heads():
+    """same packing with a GQA head layout small enough for the oracle to cover every head"""
+    _run_and_compare(dict(kind="zigzag_varlen", W=8, cu=[0, 1024, 10240, 32768], H=4, Hk=2, D=128, seed=114))
 
 
 def test_config3_zigzag_w4_gqa_reduced():
@@ -85,20 +108,27 @@ def test_config3_zigzag_w4_gqa_reduced():
     _run_and_compare(dict(kind="zigzag", W=4, B=1, S=8192, H=8, Hk=2, D=128, seed=103))
 
 
-def test_config5_hf_adapter_qwen3_w2():
+@pytest.mark.parametrize("W,layers,cu", [
+    (2, 2, [0, 750, 2250, 4096]),               # quick form
+    (8, 4, [0, 3000, 9000, 16384]),             # BASELINE.json configs[4] as stated: W = 8, 16384 tokens
+])
+def test_config5_hf_adapter_qwen3(W, layers, cu):
+    """llama3_flash_attn_varlen_func through the HF adapter on a random-init Qwen3-0.6B layer stack
+    (hidden 1024, 16 q / 8 kv heads, head_dim 128, intermediate 3072; vocabulary cut to 4096 and 4 of the
+    28 layers so that 8 model replicas + the eager references share one GPU), heads_k_stride 1, packed
+    sequences deliberately not rank aligned (SURVEY §8d cfg 5)."""
     import _adapter_worker as AW
     from conftest import free_port
 
-    cfg = dict(hidden_size=1024, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=16,
-               num_key_value_heads=8, head_dim=128, vocab_size=4096, max_position_embeddings=8192)
-    cu = [0, 750, 2250, 4096]                   # not rank aligned (as SURVEY §8d cfg 5, scaled)
+    cfg = dict(hidden_size=1024, intermediate_size=3072, num_hidden_layers=layers, num_attention_heads=16,
+               num_key_value_heads=8, head_dim=128, vocab_size=4096, max_position_embeddings=16384)
     dev = torch.device("cuda:0")
     # flash-attention style criterion (SURVEY §8c): against an fp32 eager reference of the same model,
     # the bf16 ring model may be at most 2x as far off as the bf16 eager model (+ a small floor)
     ref_logits, ref_grads = AW.reference(cfg, cu, torch.float32, dev)
     bf_logits, bf_grads = AW.reference(cfg, cu, torch.bfloat16, dev)
     torch.cuda.empty_cache()
-    logits, grads = AW.run_world(2, cfg, cu, use_hip=True, heads_k_stride=1, port=free_port())
+    logits, grads = AW.run_world(W, cfg, cu, use_hip=True, heads_k_stride=1, port=free_port())
     scale = ref_logits.abs().max().item()
     e_ring = (logits - ref_logits).abs().max().item()
     e_bf = (bf_logits - ref_logits).abs().max().item()

@@ -23,9 +23,38 @@ def test_schedules_match_reference_golden(W):
 
 
 @pytest.mark.parametrize("W", [2, 4, 8])
+def test_zigzag_fp32_wire_matches_golden(W, monkeypatch):
+    """gather exchange with fp32 dK/dV contributions + reduce-scatter (RFA_DKV_WIRE=fp32; the default sends the
+    io dtype and sums at the owner, exercised by the test above)."""
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")
+    monkeypatch.setenv("RFA_DKV_WIRE", "fp32")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
+def test_exchange_mode_auto_threshold(monkeypatch):
+    """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
+    import torch
+    from ring_flash_attn.zigzag_ring_flash_attn import exchange_mode, gather_scratch_bytes
+
+    k = torch.empty(1, 8192, 8, 128, dtype=torch.bfloat16, device="meta")
+    monkeypatch.delenv("RFA_ZIGZAG_EXCHANGE", raising=False)
+    monkeypatch.delenv("RFA_DKV_WIRE", raising=False)
+    assert gather_scratch_bytes(k, 8, False) == 8 * 2 * k.numel() * 4          # 0.27 + 0.27 GB
+    assert exchange_mode(k, 8) == "gather"
+    big = torch.empty(1, 131072, 8, 128, dtype=torch.bfloat16, device="meta")   # 128K tokens per rank
+    assert exchange_mode(big, 8) == "ring"
+    monkeypatch.setenv("RFA_GATHER_MAX_BYTES", "1000")
+    assert exchange_mode(k, 8) == "ring"
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")
+    assert exchange_mode(big, 8) == "gather"
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
 def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
-    """RFA_ZIGZAG_EXCHANGE=ring (the reference's hop-by-hop protocol; the default is the mesh-aware
-    all-gather / reduce-scatter form exercised by the test above) gives the same golden results."""
+    """RFA_ZIGZAG_EXCHANGE=ring (the reference's hop-by-hop protocol; small shapes default to the mesh-aware
+    gather form exercised by the test above) gives the same golden results."""
     monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "ring")
     names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
     assert names
@@ -78,5 +107,43 @@ def test_torch_compile_tolerance(single_rank_group):
         out = compiled(x, causal=True)
         out.sum().backward()
         assert torch.equal(out, eager) and x.grad is not None and x.grad.shape == qkv.shape
+    finally:
+        backend.set_backend(None)
+
+
+def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
+    """BASELINE.json configs[0]: `ring_flash_attn_qkvpacked_func`, world_size 1, CPU / gloo, batch 1,
+    seq 512, nheads 4, d 64, fp32, causal — the reference's own CPU-runnable plumbing case (fixture style:
+    /root/reference/test/test_ring_flash_attn_func.py:17-36, qkv = randn(B, S, 3, H, D)).  The product
+    has no CPU / fp32 compute path by design, so the operator backend is the oracle (test hook); what is
+    checked is everything above the C ABI at this shape and dtype: packed-qkv autograd Function, W = 1
+    short-circuit, dtype plumbing (fp32 in -> fp32 out / lse / one packed fp32 gradient), against an
+    independent fp64 softmax attention with autograd."""
+    import torch
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle import flash_attn_ref as O
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    try:
+        g = torch.Generator().manual_seed(0)
+        B, S, H, D = 1, 512, 4, 64
+        qkv = torch.randn(B, S, 3, H, D, generator=g, dtype=torch.float32).requires_grad_(True)
+        dout = torch.randn(B, S, H, D, generator=g, dtype=torch.float32)
+        out, lse, _ = R.ring_flash_attn_qkvpacked_func(qkv, dropout_p=0.0, causal=True, window_size=(-1, -1),
+                                                        alibi_slopes=None, deterministic=False,
+                                                        return_attn_probs=True)
+        out.backward(dout)
+        assert out.dtype == torch.float32 and out.shape == (B, S, H, D)
+        assert lse.dtype == torch.float32 and lse.shape == (B, H, S)
+        assert qkv.grad.dtype == torch.float32 and qkv.grad.shape == qkv.shape
+
+        ref = qkv.detach().double().requires_grad_(True)
+        ro, rl = O.full_attention_fp64(ref[:, :, 0], ref[:, :, 1], ref[:, :, 2], True, D ** -0.5)
+        ro.backward(dout.double())
+        assert (out.double() - ro).abs().max() < 2e-5
+        assert (lse.double() - rl).abs().max() < 2e-5
+        assert (qkv.grad.double() - ref.grad).abs().max() < 5e-5 * max(1.0, ref.grad.abs().max().item())
     finally:
         backend.set_backend(None)
