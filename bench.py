@@ -10,13 +10,24 @@ A "step" = one forward + one backward of that operator on every rank (grad reset
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line (rank 0).  `value` = iterations/s of the whole job (max time over ranks).
-`roofline` = the dominant kernel (dK/dV backward) against the bf16 MFMA peak, timed with device
-events on the launch stream; `cpu_baseline` = the CPU oracle ("port") on a bounded sample of the
-same workload on this box's host cores (rank 0, N=1 only).
+At every N the line carries
+  * `roofline`   the dominant kernel (largest device time per launch) against the bf16 MFMA peak, timed
+                 with device events on the launch stream on rank 0, on this rank's step-0 (local causal)
+                 block — the same launch at every world size;
+  * `comm`       (N > 1) exchange form, bytes per rank per iteration, and `exposed_ms` = measured step minus
+                 the same rank-local kernel sequence with the exchange looped back to local buffers
+                 (ring_flash_attn.utils.set_loopback), max over ranks;
+  * `cpu_baseline` (N = 1) the CPU oracle ("port") on a bounded sample of the same workload on this box's
+                 host cores.
+Other workloads of the reference's benchmark suite (benchmark/benchmark_varlen_kvpacked_func.py:14-187):
+  --workload zigzag_varlen | llama3   packed sequences, 8192 tokens per rank, 4 cu_seqlens patterns cycled,
+                                      llama3 with heads_k_stride 4 — BASELINE.json configs[3]/[4] family.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,12 +44,23 @@ import torch.distributed as dist
 
 SEQ, HEADS, HEAD_DIM = 8192, 32, 128
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+# local cu_seqlens patterns of the reference's varlen benchmark (benchmark_varlen_kvpacked_func.py:54-61)
+VARLEN_PATTERNS = [[0, 8192], [0, 256, 7648, 8192], [0, 4096, 8192], [0, 3104, 6304, 7904, 8064, 8192]]
+LLAMA3_HEADS_K_STRIDE = 4          # benchmark_varlen_kvpacked_func.py:132
 
 
-def fwd_flops(world):
-    """flash-attention convention, causal = half: 4*B*H*S_tot^2*D/2, per GPU (/world)."""
-    s_tot = SEQ * world
-    return 4.0 * 1 * HEADS * s_tot * s_tot * HEAD_DIM / 2.0 / world
+def causal_fwd_flops(lengths):
+    """flash-attention convention, causal = half: sum over sequences of 4*H*L^2*D/2"""
+    return sum(4.0 * HEADS * float(L) * float(L) * HEAD_DIM / 2.0 for L in lengths)
+
+
+def fwd_flops_per_gpu(workload, world):
+    if workload == "zigzag":
+        return causal_fwd_flops([SEQ * world]) / world
+    tot = 0.0
+    for cu in VARLEN_PATTERNS:      # global sequence lengths = local lengths * world (both varlen workloads)
+        tot += causal_fwd_flops([(b - a) * world for a, b in zip(cu[:-1], cu[1:])]) / world
+    return tot / len(VARLEN_PATTERNS)
 
 
 def time_kernel(fn, iters=10, warm=2):
@@ -55,59 +77,131 @@ def time_kernel(fn, iters=10, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_breakdown(q, kv, dout, hk):
-    """per-kernel device time at N=1 through the backend (same launches the operator makes)."""
+def kernel_breakdown(q, kv, dout, cu=None):
+    """per-kernel device time of this rank's local causal block through the backend (the launches the operator
+    makes at step 0 of every world size; dense (1,S,H,D) or packed (T,H,D) with cu_seqlens)."""
     from ring_flash_attn import _C
     from ring_flash_attn.backend import get_backend
 
     be = get_backend()
-    k, v = kv[:, :, 0], kv[:, :, 1]
-    B, S, H, D = q.shape
+    varlen = cu is not None
+    if varlen:
+        k, v = kv[:, 0], kv[:, 1]
+        T, H, D = q.shape
+        lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
+        mx = int((cu[1:] - cu[:-1]).max().item())
+        vl = dict(cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=mx, max_seqlen_k=mx)
+        pre = dict(cu_seqlens_q=cu, max_seqlen_q=mx)
+    else:
+        k, v = kv[:, :, 0], kv[:, :, 1]
+        B, S, H, D = q.shape
+        lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+        vl, pre = {}, {}
     scale = D ** -0.5
     out = torch.empty_like(q)
-    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
     delta = torch.empty_like(lse)
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dq = torch.empty_like(q)
     dkc, dvc = torch.empty(k.shape, dtype=k.dtype, device=q.device), torch.empty(v.shape, dtype=v.dtype, device=q.device)
     t = {}
-    t["fwd"] = time_kernel(lambda: be.fwd(q, k, v, softmax_scale=scale, causal=True, out=out, lse=lse))
-    t["bwd_preprocess"] = time_kernel(lambda: be.bwd_preprocess(dout, out, delta))
-    common = dict(softmax_scale=scale, causal=True, dq=dq, dk=dkc, dv=dvc)
+    t["fwd"] = time_kernel(lambda: be.fwd(q, k, v, softmax_scale=scale, causal=True, out=out, lse=lse, **vl))
+    t["bwd_preprocess"] = time_kernel(lambda: be.bwd_preprocess(dout, out, delta, **pre))
+    common = dict(softmax_scale=scale, causal=True, dq=dq, dk=dkc, dv=dvc, **vl)
     t["bwd_dq"] = time_kernel(lambda: be.bwd(dout, q, k, v, lse, delta, phases=_C.BWD_COMPUTE | _C.BWD_SKIP_DKDV, **common))
     t["bwd_dkdv"] = time_kernel(lambda: be.bwd(dout, q, k, v, lse, delta, phases=_C.BWD_COMPUTE | _C.BWD_SKIP_DQ, **common))
-    t["bwd_reduce"] = time_kernel(lambda: be.bwd(dout, q, k, v, lse, delta, phases=_C.BWD_REDUCE, **common))
     return t
 
 
-def cpu_baseline(hk):
-    """The CPU oracle (a port: oracle/flash_attn_ref.py, the restated flash_attn arithmetic the
-    reference would run per block) on a bounded sample: ONE kv-head group (H/Hk q heads) at the full
-    S=8192 causal shape, fwd+bwd once, scaled by the number of groups.  World size 1: the zigzag
-    schedule degenerates to a single causal block, so no merge/communication is involved."""
+def kernels_digest():
+    """content hash of the device sources: profiles/*traffic.json is only valid for the kernels it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ring-flash-attention_amd", "csrc")
+    for n in sorted(os.listdir(d)):
+        if n.endswith((".hip", ".hpp", ".cpp")):
+            h.update(open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel, hk):
+    """HBM bytes per launch from the committed PMC pass (counters cannot be collected inside the timed process).
+    Returns (bytes or None, note)."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for n in sorted(os.listdir(pdir)):
+        if n.endswith("_traffic.json"):
+            best = n
+    if best is None or hk != 8:
+        return None, "no PMC traffic pass committed for this configuration"
+    tr = json.load(open(os.path.join(pdir, best)))
+    if tr.get("kernels_sha16") != kernels_digest():
+        sys.stderr.write(f"bench.py: profiles/{best} was collected on different kernel sources "
+                         f"({tr.get('kernels_sha16')} vs {kernels_digest()}): roofline.traffic withheld — "
+                         f"re-run profiles/collect_pmc.sh\n")
+        return None, f"profiles/{best} is stale for the current kernel sources (re-run profiles/collect_pmc.sh)"
+    if kernel not in tr:
+        return None, f"profiles/{best} has no entry for {kernel}"
+    return tr[kernel]["hbm_bytes_per_launch"], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+
+
+def cpu_model():
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hk, full):
+    """The CPU oracle (a port: oracle/flash_attn_ref.py, the restated flash_attn arithmetic the reference would
+    run per block; at world size 1 the reference's zigzag schedule is exactly one such block, one first-block
+    merge (a copy) and one cast — /root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:28-88 — and the
+    reference tree itself does not exist on the GPU box).  Default: a bounded sample — ONE kv-head group (H/Hk
+    q heads) at the full S = 8192 causal shape, fwd+bwd, after a warm-up pass on a quarter-length problem —
+    scaled by the number of groups and labelled extrapolated.  --cpu-baseline-full times all groups."""
     from oracle import flash_attn_ref as O
 
     g = HEADS // hk
+    groups = hk if full else 1
     gen = torch.Generator().manual_seed(42)
-    q = torch.randn(1, SEQ, g, HEAD_DIM, generator=gen).to(torch.bfloat16)
-    k = torch.randn(1, SEQ, 1, HEAD_DIM, generator=gen).to(torch.bfloat16)
-    v = torch.randn(1, SEQ, 1, HEAD_DIM, generator=gen).to(torch.bfloat16)
-    do = torch.randn(1, SEQ, g, HEAD_DIM, generator=gen).to(torch.bfloat16)
+    q = torch.randn(1, SEQ, g * groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
+    k = torch.randn(1, SEQ, groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
+    v = torch.randn(1, SEQ, groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
+    do = torch.randn(1, SEQ, g * groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
     scale = HEAD_DIM ** -0.5
+
+    def once(n):
+        out, lse, _, _ = O._flash_attn_forward(q[:, :n], k[:, :n], v[:, :n], 0.0, scale, True)
+        dq, dk, dv = torch.empty_like(q[:, :n]), torch.empty_like(k[:, :n]), torch.empty_like(v[:, :n])
+        O._flash_attn_backward(do[:, :n], q[:, :n], k[:, :n], v[:, :n], out, lse, dq, dk, dv, 0.0, scale, True)
+
+    once(SEQ // 4)                   # warm-up: thread pool, allocator, first-touch
     t0 = time.perf_counter()
-    out, lse, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, True)
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    O._flash_attn_backward(do, q, k, v, out, lse, dq, dk, dv, 0.0, scale, True)
+    once(SEQ)
     dt = time.perf_counter() - t0
-    full = dt * hk
+    total = dt * (hk // groups)
     return {
-        "value": 1.0 / full,
+        "value": 1.0 / total,
         "unit": "iters/sec",
         "cores": torch.get_num_threads(),
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
         "kind": "port",
-        "sample": f"1 of {hk} kv-head groups ({g} q heads), full S={SEQ} causal fwd+bwd once "
-                  f"({dt:.2f} s), scaled x{hk}",
+        "extrapolated": not full,
+        "sample": (f"all {hk} kv-head groups, full S={SEQ} causal fwd+bwd, one timed pass after a warm-up ({dt:.2f} s)"
+                   if full else
+                   f"1 of {hk} kv-head groups ({g} q heads), full S={SEQ} causal fwd+bwd, one timed pass after a "
+                   f"warm-up ({dt:.2f} s), scaled x{hk}"),
     }
+
+
+def comm_bytes_per_iter(mode, wire_fp32, world, hk):
+    """xGMI bytes SENT per rank per iteration (fwd + bwd) of the dense zigzag exchange"""
+    m = 2 * SEQ * hk * HEAD_DIM * 2                      # K + V of one rank, bf16
+    if mode == "ring":                                   # BASELINE.md §2: (W-1) M fwd, (W-1) M + W 2M (fp32 dK/dV) bwd
+        return (world - 1) * m + (world - 1) * m + world * 2 * m
+    contrib = (2 * m) if wire_fp32 else m                # dK + dV contribution for one chunk
+    return (world - 1) * m + (world - 1) * m + (world - 1) * contrib
 
 
 def main():
@@ -116,9 +210,23 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--kv-heads", type=int, default=8, help="8 = the reference benchmark's GQA; 32 = MHA")
+    ap.add_argument("--workload", default="zigzag", choices=["zigzag", "zigzag_varlen", "llama3"],
+                    help="zigzag = the BASELINE.json headline; the others mirror benchmark_varlen_kvpacked_func.py")
+    ap.add_argument("--exchange", default=None, choices=["auto", "gather", "ring"],
+                    help="dense zigzag exchange form (default: RFA_ZIGZAG_EXCHANGE or auto)")
+    ap.add_argument("--wire", default=None, choices=["io", "fp32"], help="dK/dV dtype on the wire (gather form)")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="N=1 only: additionally time rank --virtual-rank's kernel sequence of a job of this world size "
+                         "with the exchange looped back to local buffers (compute-only cost of the multi-step path)")
+    ap.add_argument("--virtual-rank", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="time all kv-head groups (about 8x longer)")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
+    if args.exchange:
+        os.environ["RFA_ZIGZAG_EXCHANGE"] = args.exchange
+    if args.wire:
+        os.environ["RFA_DKV_WIRE"] = args.wire
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,50 +254,100 @@ def main():
         os.close(saved_stdout)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from ring_flash_attn import zigzag_ring_flash_attn_kvpacked_func as fn
+    import ring_flash_attn as R
+    from ring_flash_attn import utils as rfa_utils
+    from ring_flash_attn.zigzag_ring_flash_attn import exchange_mode, _wire_fp32
 
     hk = args.kv_heads
+    wl = args.workload
     torch.manual_seed(42 + rank)
-    q = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
-    kv = torch.randn(1, SEQ, 2, hk, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
-    dout = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16)
+    if wl == "zigzag":
+        q = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        kv = torch.randn(1, SEQ, 2, hk, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        dout = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16)
+        fn = R.zigzag_ring_flash_attn_kvpacked_func
+
+        def call(i):
+            return fn(q, kv, causal=True, window_size=(-1, -1), alibi_slopes=None, deterministic=False,
+                      return_attn_probs=False)
+    else:
+        q = torch.randn(SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        kv = torch.randn(SEQ, 2, hk, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
+        dout = torch.randn(SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16)
+        cus = [torch.tensor(c, device=dev, dtype=torch.int32) for c in VARLEN_PATTERNS]
+        maxs = [max(b - a for a, b in zip(c[:-1], c[1:])) for c in VARLEN_PATTERNS]
+        if wl == "zigzag_varlen":
+            fn = R.zigzag_ring_flash_attn_varlen_kvpacked_func
+
+            def call(i):
+                j = i % len(cus)
+                return fn(q, kv, cus[j], maxs[j], causal=True, window_size=(-1, -1), alibi_slopes=None,
+                          deterministic=False, return_attn_probs=False)
+        else:
+            fn = R.llama3_flash_attn_varlen_kvpacked_func
+            prep = [R.llama3_flash_attn_prepare_cu_seqlens(torch.tensor(c, dtype=torch.int32) * world, True, rank, world)
+                    for c in VARLEN_PATTERNS]
+            prep = [(cq.to(dev), ck.to(dev), mq, mk, sl) for cq, ck, mq, mk, sl in prep]
+
+            def call(i):
+                cq, ck, mq, mk, sl = prep[i % len(prep)]
+                return fn(q, kv, cq, ck, mq, mk, heads_k_stride=LLAMA3_HEADS_K_STRIDE, local_k_slice=sl, causal=True,
+                          window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False)
+
+    counter = [0]
 
     def step():
         q.grad = None
         kv.grad = None
-        out = fn(q, kv, causal=True, window_size=(-1, -1), alibi_slopes=None, deterministic=False,
-                 return_attn_probs=False)
+        out = call(counter[0])
+        counter[0] += 1
         out.backward(dout)
+
+    def timed(n):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev if world > 1 else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return tmax.item()
 
     # device spin-up (not a measurement knob): the MI355X needs some tens of milliseconds of load to leave
     # its idle clocks; without it the W warm-up steps (W x ~2 ms) end while the clocks are still ramping and
     # the timed region measures the ramp, not the kernels.  Untimed, bounded, reported in the JSON line.
     spin_s = float(os.environ.get("RFA_BENCH_SPINUP_S", "0.3"))
-    t_spin = time.perf_counter()
-    while spin_s > 0 and time.perf_counter() - t_spin < spin_s:
-        step()
+    if world == 1:
+        t_spin = time.perf_counter()
+        while spin_s > 0 and time.perf_counter() - t_spin < spin_s:
+            step()
+            torch.cuda.synchronize()
+    elif spin_s > 0:
+        # every rank must make the same number of collective calls: a fixed count instead of a wall-clock bound
+        for _ in range(8):
+            step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if world > 1 else "cpu")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = tmax.item()
+    counter[0] = 0
+    elapsed = timed(args.steps)
 
     ms = elapsed / args.steps * 1e3
     its = args.steps / elapsed
-    per_gpu_flops = 3.5 * fwd_flops(world)
+    per_gpu_flops = 3.5 * fwd_flops_per_gpu(wl, world)
+    names = {"zigzag": "zigzag_ring_flash_attn_kvpacked_func", "zigzag_varlen": "zigzag_ring_flash_attn_varlen_kvpacked_func",
+             "llama3": "llama3_flash_attn_varlen_kvpacked_func"}
+    shape = (f"per-rank q=(1,{SEQ},{HEADS},{HEAD_DIM}) kv=(1,{SEQ},2,{hk},{HEAD_DIM})" if wl == "zigzag" else
+             f"per-rank q=({SEQ},{HEADS},{HEAD_DIM}) kv=({SEQ},2,{hk},{HEAD_DIM}), 4 cu_seqlens patterns cycled"
+             + (f", heads_k_stride {LLAMA3_HEADS_K_STRIDE}" if wl == "llama3" else ""))
     result = {
-        "metric": "iters/sec fwd+bwd zigzag_ring, seq=8192*ws, h=32, d=128 bf16",
+        "metric": "iters/sec fwd+bwd zigzag_ring, seq=8192*ws, h=32, d=128 bf16" if wl == "zigzag"
+                  else f"iters/sec fwd+bwd {wl}, 8192 tokens/rank, h=32, d=128 bf16",
         "value": its,
         "unit": "iters/sec",
         "n_gpus": world,
@@ -203,8 +361,7 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"zigzag_ring_flash_attn_kvpacked_func fwd+bwd, per-rank q=(1,{SEQ},{HEADS},{HEAD_DIM}) "
-                        f"kv=(1,{SEQ},2,{hk},{HEAD_DIM}) bf16 causal, total seq {SEQ * world}",
+            "workload": f"{names[wl]} fwd+bwd, {shape} bf16 causal, total seq {SEQ * world}",
             "kv_heads": hk,
             "world_size": world,
         },
@@ -212,40 +369,80 @@ def main():
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
     }
 
-    if rank == 0 and world == 1 and not args.no_breakdown:
+    # ---- exchange accounting (N > 1): the same rank-local kernel sequence with the exchange looped back
+    if world > 1:
+        mode = exchange_mode(kv.detach()[:, :, 0], world) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
+        rfa_utils.set_loopback((rank, world))
+        try:
+            for _ in range(2):
+                step()
+            counter[0] = 0
+            comp = timed(args.steps) / args.steps * 1e3
+        finally:
+            rfa_utils.set_loopback(None)
+        result["comm"] = {
+            "exchange": mode,
+            "dkv_wire": ("fp32" if (_wire_fp32() or mode == "ring") else "bf16") if wl == "zigzag" else None,
+            "backend": dist.get_backend(),
+            "world_size_observed": dist.get_world_size(),
+            "bytes_sent_per_rank_per_iter": comm_bytes_per_iter(mode, _wire_fp32(), world, hk) if wl == "zigzag" else None,
+            "compute_only_ms": comp,
+            "exposed_ms": ms - comp,
+            "note": "compute_only = this rank's exact kernel sequence with the exchange looped back to local buffers "
+                    "(ring_flash_attn.utils.set_loopback), max over ranks; exposed = ms_per_step - compute_only",
+        }
+
+    if world == 1 and args.virtual_world > 1:
+        vw = args.virtual_world
+        vr = args.virtual_rank if args.virtual_rank >= 0 else vw // 2 - 1 + (vw > 2)
+        rfa_utils.set_loopback((vr, vw))
+        try:
+            for _ in range(2):
+                step()
+            counter[0] = 0
+            vms = timed(args.steps) / args.steps * 1e3
+        finally:
+            rfa_utils.set_loopback(None)
+        result["virtual_ring"] = {
+            "world": vw, "rank": vr, "ms_per_step": vms, "ideal_ms": vw * ms, "efficiency": vw * ms / vms,
+            "exchange": exchange_mode(kv.detach()[:, :, 0], vw) if wl == "zigzag" else None,
+            "note": "one rank's exact kernel sequence at this world size, exchange looped back to local buffers; "
+                    "ideal = world x the measured world-size-1 step",
+        }
+
+    if rank == 0 and not args.no_breakdown:
         with torch.no_grad():
-            t = kernel_breakdown(q.detach(), kv.detach(), dout, hk)
-        f = fwd_flops(1)
+            if wl == "zigzag":
+                t = kernel_breakdown(q.detach(), kv.detach(), dout)
+                f = causal_fwd_flops([SEQ])
+            else:
+                cu_b = torch.tensor(VARLEN_PATTERNS[1], device=dev, dtype=torch.int32)
+                t = kernel_breakdown(q.detach(), kv.detach(), dout, cu_b)
+                f = causal_fwd_flops([b - a for a, b in zip(VARLEN_PATTERNS[1][:-1], VARLEN_PATTERNS[1][1:])])
         # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
         # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of
         # S and dP inside the dQ kernel is NOT credited)
         algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
         dom = max(algo, key=lambda n: t[n])
         ach = algo[dom] / (t[dom] * 1e-3) / 1e12
+        kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_kernel"}[dom]
+        traffic, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
         result["roofline"] = {
-            "kernel": {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_kernel"}[dom],
+            "kernel": kn,
+            "launch": "this rank's local causal block (step 0 of every world size)",
             "bound": "mfma",
             "achieved": ach,
             "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": note,
             "avg_launch_ms": t[dom],
         }
-        # HBM bytes per launch come from the committed PMC pass (profiles/r01_traffic.json), not from
-        # this run: counters cannot be collected inside the timed process
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            kn = result["roofline"]["kernel"]
-            if hk == 8 and kn in tr:
-                result["roofline"]["traffic"] = tr[kn]["hbm_bytes_per_launch"]
-                result["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
-        except Exception:
-            pass
         result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t.items()}
         result["kernels_tflops"] = {n: algo[n] / (t[n] * 1e-3) / 1e12 for n in algo}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(hk)
+        result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RFA_ABI_VERSION 1
+#define RFA_ABI_VERSION 2
 
 typedef enum {
   RFA_OK = 0,
@@ -65,7 +65,8 @@ typedef enum {
   RFA_ERR_SHAPE = -5,       /* negative / zero extents                         */
   RFA_ERR_ALIGN = -6,       /* pointer or stride breaks the 16-byte contract   */
   RFA_ERR_LAUNCH = -7,      /* hipLaunchKernel reported an error               */
-  RFA_ERR_ARGS = -8         /* inconsistent flag / pointer combination         */
+  RFA_ERR_ARGS = -8,        /* inconsistent flag / pointer combination         */
+  RFA_ERR_ATTR = -9         /* per-device dynamic-LDS opt-in of a kernel failed */
 } rfa_status;
 
 typedef enum { RFA_BF16 = 0, RFA_F16 = 1 } rfa_dtype;
@@ -150,6 +151,13 @@ typedef struct {
    * dk/dv accumulators it will add into (zigzag_ring_flash_attn.py:172-187).  With phases != 0
    * the workspace is always required. */
   int32_t phases;
+  /* Optional dS spill scratch (io dtype, rfa_bwd_ds_scratch_bytes() bytes; NULL = not used).  When given and
+   * rfa_bwd_ds_scratch_bytes() is non-zero for the call, the backward runs 5 GEMMs instead of 7: the dK/dV
+   * kernel stores dS = P*(dP - delta) of every (32 query x 32 key) block it visits and dQ is computed by a
+   * streaming GEMM over those blocks instead of recomputing S and dP (csrc/rfa_dqs.hip).  The contents are
+   * only meaningful between the two kernels of one call (or between a RFA_BWD_SKIP_DQ call and the matching
+   * RFA_BWD_SKIP_DKDV call).  Eligible: dense calls (cu_seqlens NULL, no half selection) with D == 128. */
+  void *ds_scratch;
 } rfa_bwd_args;
 
 enum {
@@ -189,6 +197,8 @@ const char *rfa_strerror(int status);
 int rfa_fwd(const rfa_fwd_args *args, void *stream);
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
+/* bytes of ds_scratch the call would use (B*H*ceil(Sq/32)*ceil(Sk/32)*2048), or 0 if it is not eligible */
+int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args *args);
 int rfa_bwd(const rfa_bwd_args *args, void *stream);
 int rfa_merge(const rfa_merge_args *args, void *stream);
 

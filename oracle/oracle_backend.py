@@ -50,9 +50,6 @@ def _lse_rows(t, b, s, l):          # (B,H,S) or (H,T) -> (H,l) view
 class OracleBackend:
     name = "oracle"
 
-    def __init__(self):
-        self._pending = None
-
     # ------------------------------------------------------------------ forward
     def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
             max_seqlen_q=None, max_seqlen_k=None, q_half=0, k_half=0, out=None, lse=None,
@@ -90,7 +87,7 @@ class OracleBackend:
     def bwd(self, dout, q, k, v, lse, delta, *, softmax_scale, causal, cu_seqlens_q=None,
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=0, k_half=0,
             dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None, acc_init=False,
-            deterministic=False, phases=BWD_ALL):
+            deterministic=False, phases=BWD_ALL, partials=None):
         pairs = list(zip(_seqs(q, cu_seqlens_q, q_half), _seqs(k, cu_seqlens_k, k_half)))
         kv_init = acc_init or bool(phases & 16)          # RFA_BWD_KV_OVERWRITE (include/rfa.h)
         phases &= 3
@@ -107,9 +104,13 @@ class OracleBackend:
                 else:
                     _rows(dq, bq, qs, ql).copy_(gq)
                 pend.append((gk, gv))
-            self._pending = pend
+            if phases == BWD_COMPUTE:
+                return pend                      # the token the matching BWD_REDUCE call must be given
+            partials = pend
         if phases in (BWD_ALL, BWD_REDUCE):
-            for ((bq, qs, ql), (bk, ks, kl)), (gk, gv) in zip(pairs, self._pending):
+            if partials is None:
+                raise RuntimeError("a BWD_REDUCE call needs the `partials` its BWD_COMPUTE call returned")
+            for ((bq, qs, ql), (bk, ks, kl)), (gk, gv) in zip(pairs, partials):
                 if dk_acc is not None:
                     tk, tv = _rows(dk_acc, bk, ks, kl), _rows(dv_acc, bk, ks, kl)
                     tk.copy_(gk.float() if kv_init else tk + gk.float())
@@ -117,7 +118,7 @@ class OracleBackend:
                 else:
                     _rows(dk, bk, ks, kl).copy_(gk)
                     _rows(dv, bk, ks, kl).copy_(gv)
-            self._pending = None
+        return None
 
     # ------------------------------------------------------------------ side kernels
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):

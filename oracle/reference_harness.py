@@ -40,7 +40,7 @@ def load_reference(provider="oracle"):
 
     provider = "oracle": `flash_attn` is the CPU restatement (oracle/flash_attn_ref.py) — the golden
     generator.  provider = "shim": `flash_attn` is THIS repo's compatibility package
-    (ring-flash-attention_amd/flash_attn, INTEGRATION.md route B) — used by the test that runs the
+    (ring-flash-attention_amd/shims/flash_attn, INTEGRATION.md route B) — used by the test that runs the
     unmodified reference schedules through the shipped operator interface (fresh process only: the
     reference modules bind `flash_attn` at import time)."""
     if not available():
@@ -48,8 +48,9 @@ def load_reference(provider="oracle"):
     sys.dont_write_bytecode = True
     if provider == "shim":
         pkg_root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ring-flash-attention_amd")
-        if pkg_root not in sys.path:
-            sys.path.insert(0, pkg_root)
+        for p in (pkg_root, os.path.join(pkg_root, "shims")):     # ring_flash_attn (backend) + the opt-in flash_attn shim
+            if p not in sys.path:
+                sys.path.insert(0, p)
         if getattr(sys.modules.get("flash_attn"), "_rfa_oracle_stub", False) or "ref_ring_flash_attn" in sys.modules:
             raise RuntimeError("load_reference(provider='shim') needs a process that has not loaded the oracle stub")
         import flash_attn  # noqa: F401  (the shipped compatibility package)

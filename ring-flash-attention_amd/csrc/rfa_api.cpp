@@ -26,6 +26,10 @@ inline int check_common(int dtype, int H, int Hk, int D, int B) {
   return RFA_OK;
 }
 
+inline int launch_status(int rc) {
+  return rc == kLaunchOk ? RFA_OK : (rc == kLaunchAttrFailed ? RFA_ERR_ATTR : RFA_ERR_LAUNCH);
+}
+
 inline int eff_len(int S, int half) { return half == RFA_HALF_FULL ? S : (S + 1) / 2; }
 
 }  // namespace
@@ -45,6 +49,7 @@ const char* rfa_strerror(int status) {
     case RFA_ERR_ALIGN: return "pointer/stride violates the 16-byte alignment contract";
     case RFA_ERR_LAUNCH: return "HIP kernel launch failed";
     case RFA_ERR_ARGS: return "inconsistent flag / pointer combination";
+    case RFA_ERR_ATTR: return "could not opt the kernel into its dynamic LDS size on this device";
     default: return "unknown rfa status";
   }
 }
@@ -84,7 +89,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.scale = a->softmax_scale;
   const int rows = fwd_qrows_per_block();
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
-  return launch_fwd(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
+  return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
 }
 
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {
@@ -118,6 +123,16 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
   if (!bwd_single_phase(a)) return true;
   return a->dk_acc != nullptr && !bwd_kv_direct(a);
+}
+
+static bool bwd_spill_eligible(const rfa_bwd_args* a) {
+  return a->cu_seqlens_q == nullptr && a->cu_seqlens_k == nullptr && a->D == kHeadDim &&
+         a->q_half == RFA_HALF_FULL && a->k_half == RFA_HALF_FULL && a->B > 0 && a->Sq > 0 && a->Sk > 0;
+}
+
+int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
+  if (!a || !bwd_spill_eligible(a)) return 0;
+  return (int64_t)a->B * a->H * ((a->Sq + 31) / 32) * ((a->Sk + 31) / 32) * kDsBlockBytes;
 }
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
@@ -187,8 +202,21 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   const bool do_reduce = bwd_single_phase(a) || (a->phases & RFA_BWD_REDUCE);
   const int kv_init = (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE)) ? 1 : 0;
   if (do_compute) {
-    if (!(a->phases & RFA_BWD_SKIP_DQ) && launch_bwd_dq(p, a->dtype, st)) return RFA_ERR_LAUNCH;
-    if (!(a->phases & RFA_BWD_SKIP_DKDV) && launch_bwd_dkdv(p, a->dtype, st)) return RFA_ERR_LAUNCH;
+    const bool spill = a->ds_scratch != nullptr && bwd_spill_eligible(a);
+    if (spill) {
+      // 5-GEMM form: dK/dV kernel first (it stores dS), then dQ streams dS back
+      if (!aligned16(a->ds_scratch)) return RFA_ERR_ALIGN;
+      p.ds = a->ds_scratch;
+      if (!(a->phases & RFA_BWD_SKIP_DKDV))
+        if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
+      if (!(a->phases & RFA_BWD_SKIP_DQ))
+        if (int rc2 = launch_bwd_dq_from_ds(p, a->dtype, st)) return launch_status(rc2);
+    } else {
+      if (!(a->phases & RFA_BWD_SKIP_DQ))
+        if (int rc2 = launch_bwd_dq(p, a->dtype, st)) return launch_status(rc2);
+      if (!(a->phases & RFA_BWD_SKIP_DKDV))
+        if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
+    }
   }
   if (ws && do_reduce) {
     for (int which = 0; which < 2; ++which) {

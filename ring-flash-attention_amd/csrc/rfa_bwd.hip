@@ -10,11 +10,12 @@
 //   * dq_kernel    : a workgroup owns 256 query rows, streams K/V tiles through LDS
 //                    (S,dP recomputed per tile), accumulates dQ in registers, and either
 //                    stores it or adds it into a caller fp32 accumulator (ring steps).
-//   * dkdv_kernel  : a workgroup owns 128 keys of ONE query head (K, V rows resident in LDS),
-//                    streams Q/dO tiles through LDS, accumulates dK,dV in registers (8 waves =
-//                    4 key blocks x 2 sub-tile parities).  GQA group reduction is a separate
-//                    HBM-bound kernel (rfa_aux.hip: reduce_kernel), like flash_attn's
-//                    dk_expanded + sum.
+//   * dkdv_kernel  : a workgroup owns 128 keys of ONE K/V head (its V rows resident in LDS, each
+//                    wave's K rows in registers), streams the Q/dO tiles of ALL query heads of that
+//                    K/V group through LDS and accumulates dK,dV of the whole group in registers
+//                    (8 waves = 4 key blocks x 2 sub-tile parities) — no per-head partials and no
+//                    group-reduction pass.  rfa_aux.hip: reduce_kernel only serves accumulate /
+//                    two-phase calls (workspace partials -> fp32 accumulators).
 // Lane ownership mirrors the forward kernel (see rfa_common.hpp): after the first GEMM a
 // lane owns one query row (dQ kernel) or one key (dK/dV kernel), and the probabilities go
 // straight from the accumulator registers into the B operand of the second GEMM.
@@ -35,6 +36,9 @@
 #endif
 #ifndef RFA_KV_PRIO
 #define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral)
+#endif
+#ifndef RFA_SPILL_AUX
+#define RFA_SPILL_AUX 2      // cache policy bits of the dS spill stores: 2 = nt (streamed once; 0: dkdv +3 %)
 #endif
 #ifndef RFA_KV_PIN
 #define RFA_KV_PIN 1         // pin the LDS-read / MFMA interleave with sched_group_barrier (0: +5 %)
@@ -323,7 +327,7 @@ constexpr int kKvStatBytes = 2 * kKvQ * 4;         // lse[64] + delta[64] per st
 constexpr int kKvKvBytes = kKvKeys * kRowBytes;    // 32 KiB per K / V tile
 constexpr int kKvSmem = 2 * kKvKvBytes + 4 * kKvTileBytes + 2 * kKvStatBytes;   // 129 KiB
 
-template <typename T, bool kFullD>
+template <typename T, bool kFullD, bool kSpill>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -476,8 +480,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       }
     }
     if (wave < 2) {                            // wave 0 stages lse, wave 1 delta (wave-uniform descriptor)
-      const buf_rsrc_t rs = make_rsrc((wave ? dltbase : lsebase) + j * kKvQ, rows > 0 ? rows * 4 : 0);
-      statreg = buffer_load32(rs, lane * 4);   // raw value: arithmetic here would wait on the load and drain the prefetch
+      // asynchronous like the tile DMA (counted by the wait in front of write_tile): a compiler-tracked load
+      // would be protected with vmcnt(0) at its use and drain the dS spill stores issued after it every tile
+      const dma_rsrc_t rs = make_dma_rsrc((wave ? dltbase : lsebase) + j * kKvQ, rows > 0 ? rows * 4 : 0);
+      statreg = buffer_load32_async(rs, lane * 4);
     }
     dma_stage ^= kKvTileBytes;
   };
@@ -509,6 +515,15 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   int avp = av;
   pin_vgpr(aq); pin_vgpr(avp); pin_vgpr(tq[0]); pin_vgpr(tq[1]); pin_vgpr(sa); pin_vgpr(wq); pin_vgpr(ws);
 
+  // dS spill (rfa_dqs.hip): the two packed dS operands of every active (32 query x 32 key) block go to the
+  // scratch block (b, h, qt = query row / 32, kb = key / 32) in the slot order that kernel reads back:
+  // slot 16 (key>>2) + 8 i + 4 g + (key&3), i = 0 / 1 for the rows 0-15 / 16-31 of the sub-tile
+  const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
+  const int ds_nkb = (lk + 31) >> 5;
+  const int64_t ds_head_bytes = (int64_t)((lq + 31) >> 5) * ds_nkb * kDsBlockBytes;
+  const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
+  const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * 4 + kbw);
+
   const float c = p.scale * kLog2e;
   f32x16 dk[4], dv[4];
 #pragma unroll
@@ -517,10 +532,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
   load_tile();                                         // (jt0 >= jt1: zero rows, nothing is read)
+  wait_all_vmem();
+  load_landed(statreg);
   write_tile();
   wq ^= kKvTileBytes;
   ws ^= kKvStatBytes;
-  wait_all_vmem();
   __syncthreads();
 
   const int t = par;                                  // this wave's sub-tile of every Q tile
@@ -597,6 +613,20 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       {
         const vec8<T> pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 8);
         const vec8<T> ds0 = pack8<T>(dp, 0), ds1 = pack8<T>(dp, 8);
+#ifndef RFA_SPILL_PROBE
+#define RFA_SPILL_PROBE 0     // timing probes (results invalid unless 0): 1 no stores, 2 stores after the dV/dK GEMMs,
+#endif                        // 3 one store per sub-tile, 4 every store of a wave hits one L2-resident block
+        auto spill = [&]() {
+          if (!kSpill || RFA_SPILL_PROBE == 1) return;
+          const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes +
+                            ((int64_t)(2 * j + t) * ds_nkb + ds_kb) * kDsBlockBytes;
+          if (RFA_SPILL_PROBE == 4) blk = ds_b + (int64_t)(blockIdx.x * 8 + wave) * kDsBlockBytes;
+          const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds0), rb, ds_lane, 0, RFA_SPILL_AUX);
+          if (RFA_SPILL_PROBE != 3)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds1), rb, ds_lane + 128, 0, RFA_SPILL_AUX);
+        };
+        if (RFA_SPILL_PROBE != 2) spill();
         constexpr int kAhead = RFA_KV_AHEAD2;
         vec8<T> a[16];
         auto frag = [&](int i) {                       // i: [ks2][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk]
@@ -624,8 +654,16 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
 #endif
+        if (RFA_SPILL_PROBE == 2) spill();
       }
     }
+    // The DMA (and the row statistics) of tile j+1 must have landed before they are published.  vmcnt counts
+    // stores too and retires in issue order: the two dS spill stores of this sub-tile are the youngest
+    // operations and stay in flight (draining them costs a store round trip per tile: 0.93 -> 1.2 ms)
+    if (kSpill && active && RFA_SPILL_PROBE != 1 && RFA_SPILL_PROBE != 3) wait_vmem<2>();
+    else if (kSpill && active && RFA_SPILL_PROBE == 3) wait_vmem<1>();
+    else wait_all_vmem();
+    load_landed(statreg);
     if (f + 1 < ntile) write_tile();
     if (++cg >= G) {
       cg = 0;
@@ -637,7 +675,6 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     sa ^= kKvStatBytes;
     wq ^= kKvTileBytes;
     ws ^= kKvStatBytes;
-    if (kDma) wait_all_vmem();                         // the DMA of tile j+1 must have landed before the barrier
     __syncthreads();
   }
 
@@ -697,28 +734,22 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 
 template <typename T, bool kFullD>
 static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dq_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize, kDqSmem);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kFullD>, kDqSmem, attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL((dq_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kDqThreads), kDqSmem, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, bool kFullD>
+template <typename T, bool kFullD, bool kSpill>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)dkdv_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize, kKvSmem);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kFullD, kSpill>, kKvSmem, attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B;      // one workgroup per (key block, K/V head)
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  hipLaunchKernelGGL((dkdv_kernel<T, kFullD, kSpill>), dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
+  return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
@@ -728,8 +759,10 @@ int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool full = p.D == kHeadDim;
-  if (dtype == 0) return full ? launch_dkdv_t<bf16_t, true>(p, stream) : launch_dkdv_t<bf16_t, false>(p, stream);
-  return full ? launch_dkdv_t<f16_t, true>(p, stream) : launch_dkdv_t<f16_t, false>(p, stream);
+  if (full && p.ds != nullptr)
+    return dtype == 0 ? launch_dkdv_t<bf16_t, true, true>(p, stream) : launch_dkdv_t<f16_t, true, true>(p, stream);
+  if (dtype == 0) return full ? launch_dkdv_t<bf16_t, true, false>(p, stream) : launch_dkdv_t<bf16_t, false, false>(p, stream);
+  return full ? launch_dkdv_t<f16_t, true, false>(p, stream) : launch_dkdv_t<f16_t, false, false>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
 int bwd_dkdv_keys_per_block() { return kKvKeys; }

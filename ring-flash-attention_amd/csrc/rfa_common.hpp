@@ -32,6 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 typedef __attribute__((address_space(3))) char lds_t;
@@ -230,6 +231,15 @@ template <int n>
 __device__ __forceinline__ void wait_vmem() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | n);
 }
+// 4-byte buffer load hidden from the compiler's waitcnt bookkeeping (like the LDS DMA above): the caller
+// counts it in its own wait_vmem<n>() and must then pass the result through load_landed() before using it.
+// Needed where the compiler would otherwise protect the value with vmcnt(0) and drain younger stores.
+__device__ __forceinline__ float buffer_load32_async(dma_rsrc_t r, int voffset) {
+  float v;
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voffset), "s"(r.w));
+  return v;
+}
+__device__ __forceinline__ void load_landed(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ float buffer_load32(buf_rsrc_t r, int voffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 0));
 }

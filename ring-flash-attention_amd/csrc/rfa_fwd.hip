@@ -390,16 +390,12 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
 template <typename T, bool kFullD>
 static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)fwd_kernel<T, kFullD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              kFwdSmem);
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kFullD>, kFwdSmem, attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL((fwd_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kFwdThreads), kFwdSmem, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {

@@ -4,7 +4,29 @@
 #include <stdint.h>
 #include "rfa_common.hpp"
 
+#include <atomic>
+
 namespace rfa {
+
+// launcher status codes (rfa_api.cpp maps them to rfa_status)
+enum { kLaunchOk = 0, kLaunchFailed = -1, kLaunchAttrFailed = -2 };
+
+// Dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is a PER-DEVICE attribute of a kernel:
+// `done` is a bit mask indexed by device ordinal, so a process driving several GPUs opts every device in,
+// the call is made once per (kernel, device), concurrent first launches are benign (the attribute is
+// idempotent), and a failure is reported instead of surfacing later as a generic launch error.
+inline int opt_in_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return kLaunchAttrFailed;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return kLaunchOk;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return kLaunchAttrFailed;
+  }
+  done.fetch_or(bit, std::memory_order_release);
+  return kLaunchOk;
+}
 
 struct FwdParams {
   const void *q, *k, *v;
@@ -44,6 +66,7 @@ struct BwdParams {
   int q_half, k_half;
   int causal, acc_init;
   int kv_f32;          // dk / dv point to fp32 buffers (overwritten), strides in fp32 elements
+  void* ds;            // dS spill scratch (rfa_dqs.hip) or nullptr: dkdv_kernel stores its packed dS blocks there
   int nqblk, nkblk;
   float scale;
 };
@@ -75,6 +98,9 @@ int fwd_qrows_per_block();
 int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream);
+// dQ = scale * dS K from the dS blocks a preceding launch_bwd_dkdv (with p.ds set) stored; dense, D == 128
+int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream);
+constexpr int kDsBlockBytes = 2048;   // one (32 query x 32 key) block of dS in the io dtype
 int bwd_dq_rows_per_block();
 int bwd_dkdv_keys_per_block();
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);

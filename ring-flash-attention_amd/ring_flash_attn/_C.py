@@ -7,9 +7,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librfa_hip.so")
+# RFA_LIB_PATH: A/B tooling only (tools/ab_variants.py builds tuning variants of the same library)
+LIB_PATH = os.environ.get("RFA_LIB_PATH") or os.path.join(_HERE, "librfa_hip.so")
 
-RFA_ABI_VERSION = 1
+RFA_ABI_VERSION = 2
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
@@ -74,6 +75,7 @@ class BwdArgs(C.Structure):
         ("deterministic", C.c_int32),
         ("dtype", C.c_int32),
         ("phases", C.c_int32),
+        ("ds_scratch", C.c_void_p),
     ]
 
 
@@ -97,6 +99,7 @@ SYMBOLS = {
     "rfa_fwd": (C.c_int, [C.POINTER(FwdArgs), C.c_void_p]),
     "rfa_bwd_preprocess": (C.c_int, [C.POINTER(BwdPreArgs), C.c_void_p]),
     "rfa_bwd_workspace_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
+    "rfa_bwd_ds_scratch_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
     "rfa_bwd": (C.c_int, [C.POINTER(BwdArgs), C.c_void_p]),
     "rfa_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
     "rfa_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

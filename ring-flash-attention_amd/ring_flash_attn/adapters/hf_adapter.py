@@ -68,8 +68,14 @@ def use_ring_attn(flag):
 
 
 def _ring_attention(query_states, key_states, value_states, *, dropout, softmax_scale, causal,
-                    softcap=None, deterministic=None):
+                    softcap=None, deterministic=None, sliding_window=None):
     """(1,S,H,D) local q/k/v -> (1,S,H,D).  Same guards as reference hf_adapter.py:137-147."""
+    # reference hf_adapter.py:121-128: a configured sliding window that is shorter than the (local) key length
+    # is forwarded as window_size=(w, w).  The kernels have no window support, so this raises
+    # NotImplementedError in llama3_flash_attn_varlen_func instead of silently attending to everything.
+    window_size = (-1, -1)
+    if sliding_window is not None and key_states.shape[1] > sliding_window:
+        window_size = (sliding_window, sliding_window)
     assert softcap is None, "llama3_flash_attn_varlen_func does not support softcap yet."
     assert causal, "only causal attention is supported yet."
     assert query_states.size(0) == 1, "varlen data should be processed in advance."
@@ -90,6 +96,7 @@ def _ring_attention(query_states, key_states, value_states, *, dropout, softmax_
         dropout_p=dropout,
         softmax_scale=softmax_scale,
         causal=causal,
+        window_size=window_size,
         deterministic=deterministic,
         group=_STATE["group"],
     )
@@ -135,7 +142,8 @@ def ring_flash_attention_forward(
     if is_causal is None:
         is_causal = getattr(module, "is_causal", True)
     attn_output = _ring_attention(query, key, value, dropout=dropout, softmax_scale=scaling, causal=is_causal,
-                                  softcap=softcap, deterministic=kwargs.get("deterministic", None))
+                                  softcap=softcap, deterministic=kwargs.get("deterministic", None),
+                                  sliding_window=sliding_window)
     return attn_output.to(original_dtype), None
 
 
@@ -152,7 +160,7 @@ def _patched_flash_attention_forward(old_fn):
         causal = is_causal if not use_top_left_mask else (is_causal and query_length != 1)
         return _ring_attention(query_states, key_states, value_states, dropout=dropout,
                                softmax_scale=softmax_scale, causal=causal, softcap=softcap,
-                               deterministic=deterministic)
+                               deterministic=deterministic, sliding_window=sliding_window)
 
     return _flash_attention_forward
 

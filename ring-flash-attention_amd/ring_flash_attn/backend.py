@@ -58,7 +58,6 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _C.load()
-        self._ws = {}
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -76,16 +75,6 @@ class HipBackend:
             return _DTYPES[t.dtype]
         except KeyError:
             raise TypeError(f"ring_flash_attn: unsupported dtype {t.dtype} (bf16/fp16 only)") from None
-
-    def _workspace(self, device, nbytes):
-        """Per-device grow-only scratch for the dK/dV partials of accumulate / two-phase calls (caller-owned memory
-        from torch's caching allocator; the C library itself never allocates)."""
-        key = (device.type, device.index)
-        buf = self._ws.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-            self._ws[key] = buf
-        return buf
 
     # ------------------------------------------------------------------ forward
     def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
@@ -145,10 +134,14 @@ class HipBackend:
     def bwd(self, dout, q, k, v, lse, delta, *, softmax_scale, causal, cu_seqlens_q=None,
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL,
             k_half=HALF_FULL, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None,
-            acc_init=False, deterministic=False, phases=_C.BWD_ALL):
+            acc_init=False, deterministic=False, phases=_C.BWD_ALL, partials=None, ds_scratch=None):
         """dQ/dK/dV of one block.  Plain outputs (io dtype) or `+=` into fp32 accumulators.
         phases=BWD_COMPUTE / BWD_REDUCE splits the call so a ring step can overlap the kernels
-        with the arrival of the dk/dv accumulators it adds into."""
+        with the arrival of the dk/dv accumulators it adds into: the COMPUTE call RETURNS the buffer
+        holding its dK/dV partials and the REDUCE call must be handed exactly that buffer (`partials=`),
+        so interleaved backwards (other streams, re-entrant / checkpointed autograd, pipeline
+        micro-batches) can never consume each other's partials.  Scratch comes from torch's caching
+        allocator on the current stream, per call; the C library itself never allocates."""
         self._check_dev(dout, q, k, v, lse, delta, dq, dk, dv, dq_acc, dk_acc, dv_acc)
         varlen = cu_seqlens_q is not None
         a = _C.BwdArgs()
@@ -187,10 +180,36 @@ class HipBackend:
         a.deterministic = 1 if deterministic else 0
         a.dtype = self._dtype(q)
         a.phases = phases
+        # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
+        # recomputing S and dP, when the call is eligible (dense, D == 128) and the scratch stays below
+        # RFA_DS_SPILL_MAX_BYTES; RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
+        # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
+        reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
+        if ds_scratch is None and not reduce_only and _spill_enabled():
+            ds_scratch = self.bwd_ds_scratch(a, q.device)
+        if ds_scratch is not None and not reduce_only:
+            a.ds_scratch = ds_scratch.data_ptr()
         nbytes = self.lib.rfa_bwd_workspace_bytes(C.byref(a))
-        if nbytes:
-            a.workspace = self._workspace(q.device, nbytes).data_ptr()
+        ws = None
+        if (phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE):
+            if partials is None:
+                raise RuntimeError("rfa_bwd: a BWD_REDUCE call needs the `partials` buffer its BWD_COMPUTE call returned")
+            if partials.device != q.device or partials.numel() < nbytes:
+                raise RuntimeError("rfa_bwd: `partials` does not belong to this call (device / size mismatch)")
+            ws = partials
+        elif nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        if ws is not None:
+            a.workspace = ws.data_ptr()
         _C.check(self.lib.rfa_bwd(C.byref(a), _stream(q)), "rfa_bwd")
+        return ws if (phases & _C.BWD_COMPUTE) else None
+
+    def bwd_ds_scratch(self, a, device):
+        """scratch tensor for the dS spill of the call described by `a` (a filled BwdArgs), or None"""
+        sbytes = self.lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
+        if 0 < sbytes <= _spill_limit():
+            return torch.empty(sbytes, dtype=torch.uint8, device=device)
+        return None
 
     # ------------------------------------------------------------------ side kernels
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):
@@ -244,6 +263,16 @@ class HipBackend:
                                             int(max_seqlen), lse_packed.stride(1), lse_packed.stride(0),
                                             _stream(lse_packed)), "rfa_lse_unflatten")
         return dst
+
+
+def _spill_enabled() -> bool:
+    import os
+    return os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
+
+
+def _spill_limit() -> int:
+    import os
+    return int(os.environ.get("RFA_DS_SPILL_MAX_BYTES", str(8 << 30)))
 
 
 _backend = None

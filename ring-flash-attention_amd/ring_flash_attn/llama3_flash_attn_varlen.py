@@ -6,18 +6,44 @@ forward :63-158, backward :161-299, autograd :302-387, wrappers :390-504).  The 
 stream is cut into W contiguous slices; rank r attends its slice's queries against
 `local_k_slice` of the gathered keys with a bottom-right aligned causal mask.
 
-MI355X-first changes: each head group's attention writes straight into strided views of the
-final `out` / `lse` / `dq` tensors (no `torch.cat`, no per-group temporaries); delta is
-computed once; `prepare_cu_seqlens` does its integer work on one host copy of `cu_seqlens`
-instead of ~10 `.item()` syncs; world_size == 1 collapses to a single kernel for all heads.
+MI355X-first changes:
+  * `heads_k_stride` is the reference's memory knob (one all-gather + one attention launch per group of
+    that many kv heads; the reference benchmark uses 4, the HF adapter 1).  With 288 GB of HBM and a 256-CU
+    chip a launch over 1 kv head is both unnecessary and starved (config 5: 2 q heads x 8 query blocks = 16
+    workgroups), so consecutive groups are FUSED into super-groups for as long as the gathered K/V of a
+    super-group (double buffered) stays below RFA_LLAMA3_GATHER_MAX_BYTES (default 1 GiB): fewer, larger
+    collectives and launches over all fused heads.  Heads are independent, so the results do not change.
+  * forward: the all-gather of super-group i+1 runs (side stream) beside the attention of super-group i;
+  * backward: the dK/dV reduce-scatter of super-group i is posted asynchronously and runs beside the kernels
+    of super-group i+1 (two contribution buffers); only the rows OUTSIDE `local_k_slice` are zero-filled
+    (the kernel overwrites every row inside it) instead of the whole (2, T*W, g, D) buffer per group;
+  * each group's attention writes straight into strided views of the final `out` / `lse` / `dq` tensors
+    (no `torch.cat`, no per-group temporaries); delta is computed once; `prepare_cu_seqlens` does its
+    integer work on one host copy of `cu_seqlens` instead of ~10 `.item()` syncs; world_size == 1 collapses
+    to a single kernel for all heads.
 """
+import os
+
 import torch
-import torch.distributed as dist
 
 from .backend import get_backend
-from .utils import AllGatherComm as Comm, reduce_scatter
+from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async
 from ._api import _check_unsupported, _opaque
 from ._common import _as_cu
+
+
+def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world: int, head_dim: int,
+                         elt_bytes: int) -> int:
+    """kv heads per super-group: the largest multiple of heads_k_stride that divides nheads_k and keeps the
+    double-buffered gathered K/V below the budget (never smaller than heads_k_stride itself)."""
+    budget = int(os.environ.get("RFA_LLAMA3_GATHER_MAX_BYTES", str(1 << 30)))
+    per_head = 2 * total_k * world * head_dim * elt_bytes          # K and V of one kv head, all ranks
+    best = heads_k_stride
+    for m in range(1, nheads_k // heads_k_stride + 1):
+        hs = m * heads_k_stride
+        if nheads_k % hs == 0 and 2 * hs * per_head <= budget:
+            best = hs
+    return best
 
 
 def llama3_flash_attn_prepare_cu_seqlens(cu_seqlens: torch.Tensor, causal: bool, rank: int, world_size: int):
@@ -100,37 +126,34 @@ def llama3_flash_attn_varlen_forward(
 
     out = torch.empty_like(q)
     lse = torch.empty((nheads, T), dtype=torch.float32, device=q.device)
-    world_size = dist.get_world_size(process_group)
+    world_size = group_rank_world(process_group)[1]
 
     if world_size == 1:
         be.fwd(q, k[local_k_slice], v[local_k_slice], softmax_scale=softmax_scale, causal=causal,
                out=out, lse=lse, **vl)
         return out, lse
 
-    kv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
-    kv_buffer_copy = torch.empty_like(kv_buffer)
+    hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
+    groups = list(range(0, nheads_k, hs))
+    bufs = [torch.empty((2, total_k * world_size, hs, head_dim), dtype=k.dtype, device=k.device)
+            for _ in range(min(2, len(groups)))]
 
-    k_0 = k[:, :heads_k_stride].contiguous()
-    v_0 = v[:, :heads_k_stride].contiguous()
-    comm = Comm(process_group)
-    comm.all_gather(kv_buffer_copy[0], k_0)
-    comm.all_gather(kv_buffer_copy[1], v_0)
+    def post_gather(gi):
+        g0 = groups[gi]
+        comm = Comm(process_group)
+        buf = bufs[gi % 2]
+        comm.all_gather(buf[0], k[:, g0:g0 + hs].contiguous())
+        comm.all_gather(buf[1], v[:, g0:g0 + hs].contiguous())
+        return comm
 
-    for i in range(0, nheads_k, heads_k_stride):
-        comm.wait()
-        kv_buffer, kv_buffer_copy = kv_buffer_copy, kv_buffer
-
-        if i < nheads_k - heads_k_stride:
-            # all_gather the next kv slice while this group's attention runs
-            kv_slice_left = i + heads_k_stride
-            kv_slice_right = kv_slice_left + heads_k_stride
-            send_k = k[:, kv_slice_left:kv_slice_right].contiguous()
-            send_v = v[:, kv_slice_left:kv_slice_right].contiguous()
-            comm.all_gather(kv_buffer_copy[0], send_k)
-            comm.all_gather(kv_buffer_copy[1], send_v)
-
-        q_slice = slice(i * nheads // nheads_k, (i + heads_k_stride) * nheads // nheads_k)
-        be.fwd(q[:, q_slice], kv_buffer[0][local_k_slice], kv_buffer[1][local_k_slice],
+    pending = post_gather(0)
+    for gi, g0 in enumerate(groups):
+        pending.wait()
+        buf = bufs[gi % 2]
+        if gi + 1 < len(groups):
+            pending = post_gather(gi + 1)          # next super-group's K/V arrive beside this one's attention
+        q_slice = slice(g0 * nheads // nheads_k, (g0 + hs) * nheads // nheads_k)
+        be.fwd(q[:, q_slice], buf[0][local_k_slice], buf[1][local_k_slice],
                softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], **vl)
 
     return out, lse
@@ -174,7 +197,7 @@ def llama3_flash_attn_varlen_backward(
     dq = torch.empty_like(q)
     dk = torch.empty_like(k)
     dv = torch.empty_like(v)
-    world_size = dist.get_world_size(process_group)
+    world_size = group_rank_world(process_group)[1]
 
     if world_size == 1:
         if local_k_slice.start != 0 or local_k_slice.stop != total_k:
@@ -184,54 +207,58 @@ def llama3_flash_attn_varlen_backward(
                causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, **vl)
         return dq, dk, dv
 
-    kv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
-    kv_buffer_copy = torch.empty_like(kv_buffer)
-    dkv_buffer = torch.empty((2, total_k * world_size, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+    hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
+    groups = list(range(0, nheads_k, hs))
+    nbuf = min(2, len(groups))
+    rows_all = total_k * world_size
+    kv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
+    # this rank's dK/dV contributions for EVERY rank's rows (summed over ranks by the reduce-scatter)
+    dkv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
+    whole = hs == nheads_k                       # then the reduce-scatter lands in dk / dv directly
+    if not whole:                                # its output must be contiguous
+        rs_out = [torch.empty((2, total_k, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
+    lo, hi = local_k_slice.start or 0, local_k_slice.stop if local_k_slice.stop is not None else rows_all
 
-    if heads_k_stride != nheads_k:
-        kv_contiguous_buffer = torch.empty((2, total_k, heads_k_stride, head_dim), dtype=k.dtype, device=k.device)
+    def post_gather(gi):
+        g0 = groups[gi]
+        comm = Comm(process_group)
+        buf = kv_bufs[gi % 2]
+        comm.all_gather(buf[0], k[:, g0:g0 + hs].contiguous())
+        comm.all_gather(buf[1], v[:, g0:g0 + hs].contiguous())
+        return comm
 
-    comm = Comm(process_group)
-    k_0 = k[:, :heads_k_stride].contiguous()
-    v_0 = v[:, :heads_k_stride].contiguous()
-    comm.all_gather(kv_buffer_copy[0], k_0)
-    comm.all_gather(kv_buffer_copy[1], v_0)
+    def finish(job):
+        works, gi = job
+        for w in works:
+            w.wait()
+        if not whole:
+            g0 = groups[gi]
+            dk[:, g0:g0 + hs] = rs_out[gi % 2][0]
+            dv[:, g0:g0 + hs] = rs_out[gi % 2][1]
 
-    for i in range(0, nheads_k, heads_k_stride):
-        dkv_buffer.zero_()
-
-        q_slice = slice(i * nheads // nheads_k, (i + heads_k_stride) * nheads // nheads_k)
-
-        comm.wait()
-        kv_buffer, kv_buffer_copy = kv_buffer_copy, kv_buffer
-
-        if i < nheads_k - heads_k_stride:
-            kv_slice_left = i + heads_k_stride
-            kv_slice_right = kv_slice_left + heads_k_stride
-            send_k = k[:, kv_slice_left:kv_slice_right].contiguous()
-            send_v = v[:, kv_slice_left:kv_slice_right].contiguous()
-            comm.all_gather(kv_buffer_copy[0], send_k)
-            comm.all_gather(kv_buffer_copy[1], send_v)
-
-        be.bwd(dout[:, q_slice], q[:, q_slice], kv_buffer[0][local_k_slice], kv_buffer[1][local_k_slice],
+    pending = post_gather(0)
+    job = None
+    for gi, g0 in enumerate(groups):
+        pending.wait()
+        kv = kv_bufs[gi % 2]
+        if gi + 1 < len(groups):
+            pending = post_gather(gi + 1)
+        dkv = dkv_bufs[gi % 2]                   # (its previous reduce-scatter, group gi-2, was finished at gi-1)
+        if lo > 0:
+            dkv[:, :lo].zero_()
+        if hi < rows_all:
+            dkv[:, hi:].zero_()
+        q_slice = slice(g0 * nheads // nheads_k, (g0 + hs) * nheads // nheads_k)
+        be.bwd(dout[:, q_slice], q[:, q_slice], kv[0][local_k_slice], kv[1][local_k_slice],
                softmax_lse[q_slice], delta[q_slice], softmax_scale=softmax_scale, causal=causal,
-               dq=dq[:, q_slice], dk=dkv_buffer[0][local_k_slice], dv=dkv_buffer[1][local_k_slice],
+               dq=dq[:, q_slice], dk=dkv[0][local_k_slice], dv=dkv[1][local_k_slice],
                deterministic=deterministic, **vl)
-
-        if heads_k_stride != nheads_k:
-            # reduce_scatter needs a contiguous output
-            dk_i = kv_contiguous_buffer[0]
-            dv_i = kv_contiguous_buffer[1]
-        else:
-            dk_i = dk
-            dv_i = dv
-
-        reduce_scatter(dk_i, dkv_buffer[0], group=process_group)
-        reduce_scatter(dv_i, dkv_buffer[1], group=process_group)
-
-        if heads_k_stride != nheads_k:
-            dk[:, i : i + heads_k_stride] = dk_i
-            dv[:, i : i + heads_k_stride] = dv_i
+        if job is not None:
+            finish(job)                          # group gi-1's exchange ran beside the kernels just enqueued
+        dst = (dk, dv) if whole else (rs_out[gi % 2][0], rs_out[gi % 2][1])
+        job = ([reduce_scatter_async(dst[0], dkv[0], group=process_group),
+                reduce_scatter_async(dst[1], dkv[1], group=process_group)], gi)
+    finish(job)
 
     return dq, dk, dv
 

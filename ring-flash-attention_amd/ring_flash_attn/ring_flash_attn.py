@@ -110,14 +110,14 @@ def ring_flash_attn_backward(
                 be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=bwd_causal,
                        dq_acc=dq, dk_acc=dk, dv_acc=dv, acc_init=True, deterministic=deterministic)
             else:
-                be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=bwd_causal,
-                       dq_acc=dq, dk_acc=dk, dv_acc=dv, deterministic=deterministic,
-                       phases=_C.BWD_COMPUTE)
+                part = be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=bwd_causal,
+                              dq_acc=dq, dk_acc=dk, dv_acc=dv, deterministic=deterministic,
+                              phases=_C.BWD_COMPUTE)
                 d_kv_comm.wait()
                 dk, dv = next_dk, next_dv
                 be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=bwd_causal,
                        dq_acc=dq, dk_acc=dk, dv_acc=dv, deterministic=deterministic,
-                       phases=_C.BWD_REDUCE)
+                       phases=_C.BWD_REDUCE, partials=part)
         elif step != 0:
             d_kv_comm.wait()
             dk, dv = next_dk, next_dv

@@ -110,12 +110,12 @@ def ring_flash_attn_varlen_backward(
                 dq = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
                 be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv, acc_init=True, **common)
             else:
-                be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
-                       phases=_C.BWD_COMPUTE, **common)
+                part = be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
+                              phases=_C.BWD_COMPUTE, **common)
                 d_kv_comm.wait()
                 dk, dv = next_dk, next_dv
                 be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
-                       phases=_C.BWD_REDUCE, **common)
+                       phases=_C.BWD_REDUCE, partials=part, **common)
         elif step != 0:
             d_kv_comm.wait()
             dk, dv = next_dk, next_dv

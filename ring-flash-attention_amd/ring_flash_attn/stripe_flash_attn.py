@@ -122,14 +122,15 @@ def stripe_flash_attn_backward(
             be.bwd(*args, dq_acc=dq, dk_acc=dk, dv_acc=dv, acc_init=True, **common)
         else:
             # dQ (+= fp32) and per-head dK/dV partials while the dk/dv accumulators are in flight
-            be.bwd(*args, dq_acc=dq_view, dk_acc=dk, dv_acc=dv, phases=_C.BWD_COMPUTE, **common)
+            part = be.bwd(*args, dq_acc=dq_view, dk_acc=dk, dv_acc=dv, phases=_C.BWD_COMPUTE, **common)
             d_kv_comm.wait()
             dk_comm_buffer, dv_comm_buffer = dk, dv
             dk, dv = next_dk, next_dv
             if shift_causal:
-                be.bwd(*args, dq_acc=dq_view, dk_acc=dk[:, :-1], dv_acc=dv[:, :-1], phases=_C.BWD_REDUCE, **common)
+                be.bwd(*args, dq_acc=dq_view, dk_acc=dk[:, :-1], dv_acc=dv[:, :-1], phases=_C.BWD_REDUCE,
+                       partials=part, **common)
             else:
-                be.bwd(*args, dq_acc=dq_view, dk_acc=dk, dv_acc=dv, phases=_C.BWD_REDUCE, **common)
+                be.bwd(*args, dq_acc=dq_view, dk_acc=dk, dv_acc=dv, phases=_C.BWD_REDUCE, partials=part, **common)
 
         if step + 1 != kv_comm.world_size:
             kv_comm.wait()

@@ -265,8 +265,8 @@ def zigzag_ring_flash_attn_backward(
                 args = (dout[:, half:], q[:, half:], k, v, softmax_lse[:, :, half:], delta[:, :, half:])
                 dq_view = dq[:, half:]
             # phase 1: dQ (+= in fp32) and per-head dK/dV partials — overlaps the dk/dv transfer
-            be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
-                   dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_COMPUTE)
+            part = be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
+                          dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_COMPUTE)
 
             d_kv_comm.wait()
             dk_comm_buffer, dv_comm_buffer = dk, dv
@@ -276,10 +276,11 @@ def zigzag_ring_flash_attn_backward(
             if front:
                 be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
                        dk_acc=dk[:, :half], dv_acc=dv[:, :half], deterministic=deterministic,
-                       phases=_C.BWD_REDUCE)
+                       phases=_C.BWD_REDUCE, partials=part)
             else:
                 be.bwd(*args, softmax_scale=softmax_scale, causal=False, dq_acc=dq_view,
-                       dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_REDUCE)
+                       dk_acc=dk, dv_acc=dv, deterministic=deterministic, phases=_C.BWD_REDUCE,
+                       partials=part)
 
         if step + 1 != kv_comm.world_size:
             kv_comm.wait()

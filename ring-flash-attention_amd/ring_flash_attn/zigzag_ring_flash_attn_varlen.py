@@ -164,15 +164,15 @@ def zigzag_ring_flash_attn_varlen_backward(
             else:
                 halves = dict(q_half=HALF_BACK)
             common = dict(softmax_scale=softmax_scale, causal=False, deterministic=deterministic, **halves, **vl)
-            be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
-                   phases=_C.BWD_COMPUTE, **common)
+            part = be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
+                          phases=_C.BWD_COMPUTE, **common)
 
             d_kv_comm.wait()
             dk_comm_buffer, dv_comm_buffer = dk, dv
             dk, dv = next_dk, next_dv
 
             be.bwd(dout, q, k, v, softmax_lse, delta, dq_acc=dq, dk_acc=dk, dv_acc=dv,
-                   phases=_C.BWD_REDUCE, **common)
+                   phases=_C.BWD_REDUCE, partials=part, **common)
 
         if step + 1 != kv_comm.world_size:
             kv_comm.wait()

@@ -7,8 +7,9 @@ and its tests / benchmarks use the PUBLIC single-device functions as ground trut
 (test/test_zigzag_ring_flash_attn_func.py:2, benchmark/benchmark_kvpacked_func.py:1).  This module
 provides both sets with the flash_attn >= 2.7 signatures and return conventions, backed by the same
 HIP kernels (librfa_hip.so through ring_flash_attn.backend) — so the UNMODIFIED reference schedules,
-tests and benchmarks run on an MI355X by putting `ring-flash-attention_amd/` first on sys.path
-(INTEGRATION.md route B).  There is no CPU path: CPU tensors raise.
+tests and benchmarks run on an MI355X by putting `ring-flash-attention_amd/shims/` on sys.path
+(INTEGRATION.md route B; the directory is opt-in so that importing `ring_flash_attn` never shadows a real
+flash_attn install).  There is no CPU path: CPU tensors raise.
 
 Unsupported features raise instead of being silently ignored: dropout_p != 0, sliding windows,
 softcap, alibi_slopes, paged KV (block_table / leftpad_k / seqused_k), return_softmax / S_dmask.
@@ -18,7 +19,30 @@ from typing import Optional, Tuple
 
 import torch
 
-from ring_flash_attn.backend import get_backend
+
+
+def _binding():
+    """The kernels' Python binding (ring_flash_attn/_C.py + backend.py of THIS repo).  When the `ring_flash_attn`
+    on sys.path is the reference's own package (route B: its schedules, this operator), the binding is loaded
+    from its file location under the private package name `_rfa_binding` instead."""
+    try:
+        from ring_flash_attn.backend import get_backend as gb
+        return gb
+    except ImportError:
+        import importlib
+        import os
+        import sys
+        import types
+
+        if "_rfa_binding" not in sys.modules:
+            here = os.path.dirname(os.path.abspath(__file__))
+            pkg = types.ModuleType("_rfa_binding")
+            pkg.__path__ = [os.path.join(os.path.dirname(os.path.dirname(here)), "ring_flash_attn")]
+            sys.modules["_rfa_binding"] = pkg
+        return importlib.import_module("_rfa_binding.backend").get_backend
+
+
+get_backend = _binding()
 
 __all__ = [
     "_flash_attn_forward", "_flash_attn_backward", "_flash_attn_varlen_forward", "_flash_attn_varlen_backward",

@@ -65,6 +65,8 @@ def test_argument_errors_without_device(built):
     lib = _C.load()
     assert lib.rfa_abi_version() == _C.RFA_ABI_VERSION
     assert lib.rfa_fwd(None, None) == -1                      # RFA_ERR_NULL
+    assert b"dynamic LDS" in lib.rfa_strerror(-9)             # RFA_ERR_ATTR (per-device kernel attribute)
+    assert lib.rfa_strerror(-10) == b"unknown rfa status"
     a = _C.FwdArgs()
     a.B, a.H, a.Hk, a.D, a.Sq, a.Sk, a.dtype = 1, 4, 3, 64, 8, 8, 0
     assert lib.rfa_fwd(C.byref(a), None) == -4                # H % Hk
@@ -147,7 +149,13 @@ def test_flash_attn_shim_surface(built):
     `get_default_args` (utils.py:13-29) inspects: plain functions, flash_attn >= 2.7 parameter names
     (`window_size_left/right`, not `window_size`), `softcap` defaulting to 0.0."""
     import inspect
+    import sys
 
+    shims = os.path.join(ROOT, "ring-flash-attention_amd", "shims")     # opt-in root (INTEGRATION.md route B)
+    assert "flash_attn" not in sys.modules or getattr(sys.modules["flash_attn"], "__file__", "").startswith(shims), \
+        "importing ring_flash_attn must not put a `flash_attn` package on the path (it would shadow a real install)"
+    if shims not in sys.path:
+        sys.path.insert(0, shims)
     import flash_attn
     from flash_attn import flash_attn_interface as F
 

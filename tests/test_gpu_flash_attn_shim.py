@@ -1,4 +1,4 @@
-"""GPU parity of the shipped `flash_attn` compatibility package (ring-flash-attention_amd/flash_attn):
+"""GPU parity of the shipped `flash_attn` compatibility package (ring-flash-attention_amd/shims/flash_attn, an opt-in sys.path root):
 the four private operator functions the reference imports and the public single-device functions its
 tests / benchmarks use as ground truth, against the CPU oracle's functions of the same names
 (oracle/flash_attn_ref.py) on the same seeded inputs.  Tolerances as in test_gpu_kernels.py."""
@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "ring-flash-attention_amd"))
+sys.path.insert(0, os.path.join(ROOT, "ring-flash-attention_amd", "shims"))     # INTEGRATION.md route B opt-in
 BF = torch.bfloat16
 
 

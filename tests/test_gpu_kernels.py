@@ -74,10 +74,15 @@ def test_native_selftest_binary(built):
     assert "SELFTEST PASSED" in r.stdout
 
 
+@pytest.mark.parametrize("spill", ["1", "0"])
 @pytest.mark.parametrize("api,seqlen,causal", [("zigzag", 3824, True), ("ring", 3816, True), ("ring", 1000, False)])
-def test_dense_qkvpacked_reference_fixture(single_rank_group, api, seqlen, causal):
-    """reference test/test_{zigzag_,}ring_flash_attn_func.py at world_size 1: B=1, H=5, D=128 bf16."""
+def test_dense_qkvpacked_reference_fixture(single_rank_group, monkeypatch, api, seqlen, causal, spill):
+    """reference test/test_{zigzag_,}ring_flash_attn_func.py at world_size 1: B=1, H=5, D=128 bf16.
+    spill = 1: the 5-GEMM backward (dS spilled by the dK/dV kernel, dQ by rfa_dqs.hip — the default for dense
+    D = 128 calls); spill = 0: the 7-GEMM backward (dQ kernel recomputes S and dP)."""
     import ring_flash_attn as R
+
+    monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
 
     dev = _dev()
     g = torch.Generator().manual_seed(42)
@@ -244,3 +249,55 @@ def test_empty_problem_is_noop(single_rank_group):
     q = torch.empty(1, 0, 4, 128, device=dev, dtype=BF)
     out, lse, _ = R.ring_flash_attn_func(q, q, q, causal=True, return_attn_probs=True)
     assert out.shape == (1, 0, 4, 128) and lse.shape == (1, 4, 0)
+
+
+@pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk", [
+    (700, 700, True, 2, 4, 2),        # ragged tails on both axes, GQA, batch
+    (512, 1024, False, 1, 2, 2),      # ring "front" step shape: all queries x more keys, unmasked
+    (1000, 488, True, 1, 4, 1),       # more queries than keys: bottom-right alignment leaves rows without keys
+    (96, 4000, True, 1, 2, 2),        # one query block against 63 key tiles (deep dS ring)
+])
+def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk):
+    """The dS-spill backward through the backend (accumulate and plain outputs) against the CPU oracle and
+    against the recompute backward on the same inputs (they share dK/dV bit for bit: same kernel, the spill
+    only adds stores)."""
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, Sq, H, 128, generator=g).to(BF)
+    k = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
+    v = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
+    do = torch.randn(B, Sq, H, 128, generator=g).to(BF)
+    scale = 128 ** -0.5
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, causal)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out = torch.empty_like(qd)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    lse_b = torch.where(torch.isinf(lse), torch.zeros_like(lse), lse)       # rows without keys: P = 0 either way
+    res = {}
+    for spill in (True, False):
+        os.environ["RFA_BWD_DS_SPILL"] = "1" if spill else "0"
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv)
+        dqa = torch.full((B, Sq, H, 128), 3.0, dtype=torch.float32, device=dev)
+        dka = torch.zeros((B, Sk, Hk, 128), dtype=torch.float32, device=dev)
+        dva = torch.zeros_like(dka)
+        be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq_acc=dqa, dk_acc=dka, dv_acc=dva)
+        res[spill] = (dq, dk, dv, dqa)
+    os.environ.pop("RFA_BWD_DS_SPILL", None)
+    del lse_b
+    for spill in (True, False):
+        dq, dk, dv, dqa = res[spill]
+        _grads_ok(f"spill={spill}", (dq, dk, dv), (rdq, rdk, rdv))
+        _check(f"spill={spill}.dq_acc", dqa - 3.0, rdq, 1e-2, 2e-2)
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    _check("dq spill vs recompute", res[True][0], res[False][0].float(), 1e-2, 2e-2)

@@ -147,3 +147,59 @@ def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
         assert (qkv.grad.double() - ref.grad).abs().max() < 5e-5 * max(1.0, ref.grad.abs().max().item())
     finally:
         backend.set_backend(None)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_llama3_unfused_groups_match_golden(W, monkeypatch):
+    """RFA_LLAMA3_GATHER_MAX_BYTES=0 disables the super-group fusion: one all-gather / launch / reduce-scatter
+    per `heads_k_stride` group, double-buffered (the default fuses every group of these small cases into one)."""
+    monkeypatch.setenv("RFA_LLAMA3_GATHER_MAX_BYTES", "0")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "llama3"]
+    assert names
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
+def _llama3_groups_rank(rank, W, port, ret):
+    import os
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    g = torch.Generator().manual_seed(77)
+    T, H, Hk, D = 96, 8, 4, 16
+    cu = torch.tensor([0, 20, 61, 96], dtype=torch.int32)
+    q, k, v, do = (torch.randn(T, h, D, generator=g).to(torch.bfloat16) for h in (H, Hk, Hk, H))
+    L = T // W
+    sl = slice(rank * L, (rank + 1) * L)
+    cq, ck, mq, mk, ks = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, rank, W)
+    res = {}
+    for budget in ("0", str(1 << 30)):          # 4 groups of one kv head (buffers reused twice) vs one fused group
+        os.environ["RFA_LLAMA3_GATHER_MAX_BYTES"] = budget
+        ql, kl, vl = (t[sl].clone().requires_grad_(True) for t in (q, k, v))
+        out, lse, _ = R.llama3_flash_attn_varlen_func(ql, kl, vl, cq, ck, mq, mk, heads_k_stride=1, local_k_slice=ks,
+                                                      causal=True, return_attn_probs=True)
+        out.backward(do[sl])
+        res[budget] = (out.detach(), lse.detach(), ql.grad, kl.grad, vl.grad)
+    a, b = res["0"], res[str(1 << 30)]
+    ret[rank] = [i for i, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_llama3_fused_equals_unfused_four_groups():
+    """heads are independent: fusing the kv-head groups into one super-group must not change a single bit
+    (out, lse, dq, dk, dv), including across the double-buffer reuse of a 4-group loop"""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_llama3_groups_rank, args=(2, free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == [] and ret[1] == [], dict(ret)
