@@ -16,10 +16,9 @@ from ._common import _prep_qkv, _as_cu
 
 
 def _opaque(fn):
-    """`torch.compile(ring_fn)` must keep working (the reference runs every test twice, eager and
-    compiled: test/test.sh:23-25).  The operators are ctypes calls into librfa_hip.so plus
-    torch.distributed traffic, which dynamo cannot trace, so the public callables are marked opaque:
-    a compiled caller graph-breaks around them and runs them eagerly, with identical results."""
+    """The schedules are ctypes calls into librfa_hip.so interleaved with torch.distributed traffic, which dynamo
+    cannot trace: behind `torch.compiler.disable` a compiled caller graph-breaks around them and runs them
+    eagerly, with identical results (multi-rank groups; llama3)."""
     try:
         import functools
 
@@ -28,6 +27,31 @@ def _opaque(fn):
         return wrapped
     except Exception:        # very old torch without torch.compiler
         return fn
+
+
+def _single_rank(group) -> bool:
+    import torch.distributed as dist
+
+    return dist.get_world_size(group) == 1
+
+
+def _compilable(fn, lower):
+    """Public callable = `fn` (eager: the autograd Functions above, opaque to dynamo) except while dynamo is
+    TRACING it on a single-rank group: then `lower(...)` expresses the call with the registered custom
+    operators (_ops.py: rfa::attn_fwd / rfa::attn_bwd, fake kernels + autograd formula), so `torch.compile`
+    captures the operator in its graph instead of breaking it (the reference runs its tests a second time under
+    torch.compile: test/test.sh:23-25)."""
+    import functools
+
+    eager = _opaque(fn)
+
+    @functools.wraps(fn)
+    def public(*args, **kwargs):
+        if torch.compiler.is_compiling() and _single_rank(kwargs.get("group", None)):
+            return lower(*args, **kwargs)
+        return eager(*args, **kwargs)
+
+    return public
 
 
 def _check_unsupported(dropout_p, window_size, alibi_slopes):
@@ -186,9 +210,25 @@ def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None):
         return fn.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale, causal,
                         window_size, alibi_slopes, deterministic, return_attn_probs, group)
 
+    must_be_causal = prefix in ("zigzag_ring_flash_attn", "stripe_flash_attn")
+
+    def lower(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+              deterministic=False, return_attn_probs=False, group=None):
+        from ._ops import single_device_attention
+
+        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
+        return single_device_attention(q, k, v, None, 0, softmax_scale, causal, return_attn_probs)
+
+    def lower_kv(q, kv, *a, **kw):
+        return lower(q, kv[:, :, 0], kv[:, :, 1], *a, **kw)
+
+    def lower_qkv(qkv, *a, **kw):
+        return lower(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], *a, **kw)
+
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)
+    return _compilable(func, lower), _compilable(kvpacked_func, lower_kv), _compilable(qkvpacked_func, lower_qkv)
 
 
 def make_varlen_api(fn, prefix):
@@ -212,6 +252,22 @@ def make_varlen_api(fn, prefix):
         return fn.apply(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, max_seqlen, dropout_p, softmax_scale,
                         causal, window_size, alibi_slopes, deterministic, return_attn_probs, group)
 
+    must_be_causal = prefix.startswith("zigzag")
+
+    def lower(q, k, v, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+              window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+        from ._ops import single_device_attention
+
+        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
+        return single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs)
+
+    def lower_kv(q, kv, *a, **kw):
+        return lower(q, kv[:, 0], kv[:, 1], *a, **kw)
+
+    def lower_qkv(qkv, *a, **kw):
+        return lower(qkv[:, 0], qkv[:, 1], qkv[:, 2], *a, **kw)
+
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)
+    return _compilable(func, lower), _compilable(kvpacked_func, lower_kv), _compilable(qkvpacked_func, lower_qkv)

@@ -1,0 +1,109 @@
+"""`torch.library` registration of the single-device attention operator.
+
+The reference runs every test a second time under `torch.compile` (test/test.sh:23-25,
+test/test_zigzag_ring_flash_attn_func.py:105-108).  The C-ABI calls of this package are ctypes
+calls dynamo cannot trace, so they are registered as custom operators with fake (meta) kernels:
+
+    rfa::attn_fwd(q, k, v, cu_seqlens?, max_seqlen, softmax_scale, causal) -> (out, lse)
+    rfa::attn_bwd(dout, q, k, v, out, lse, cu_seqlens?, max_seqlen, softmax_scale, causal, deterministic)
+                                                                        -> (dq, dk, dv)
+
+with an autograd formula linking them.  When a public function is traced by dynamo and the process
+group has a single rank (every schedule then IS one attention call), it lowers to these operators and
+the compiled graph contains them as opaque nodes — no graph break.  With more than one rank the
+schedules interleave kernels with RCCL traffic and stay behind `torch.compiler.disable` (graph break,
+eager execution, identical results).  Eager calls never come through here: they keep the autograd
+Functions of _api.py (packed gradients written into one buffer).
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .backend import get_backend
+
+
+def _lse_shape(q: Tensor, varlen: bool):
+    if varlen:
+        return (q.shape[1], q.shape[0])                  # (H, T)
+    return (q.shape[0], q.shape[2], q.shape[1])          # (B, H, S)
+
+
+def _vl(cu_seqlens, max_seqlen):
+    if cu_seqlens is None:
+        return {}
+    return dict(cu_seqlens_q=cu_seqlens, cu_seqlens_k=cu_seqlens, max_seqlen_q=max_seqlen, max_seqlen_k=max_seqlen)
+
+
+@torch.library.custom_op("rfa::attn_fwd", mutates_args=())
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, cu_seqlens: Optional[Tensor], max_seqlen: int,
+             softmax_scale: float, causal: bool) -> Tuple[Tensor, Tensor]:
+    varlen = cu_seqlens is not None
+    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    lse = torch.empty(_lse_shape(q, varlen), dtype=torch.float32, device=q.device)
+    get_backend().fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse,
+                      **_vl(cu_seqlens, max_seqlen))
+    return out, lse
+
+
+@attn_fwd.register_fake
+def _attn_fwd_fake(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty(_lse_shape(q, cu_seqlens is not None), dtype=torch.float32, device=q.device))
+
+
+@torch.library.custom_op("rfa::attn_bwd", mutates_args=())
+def attn_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor,
+             cu_seqlens: Optional[Tensor], max_seqlen: int, softmax_scale: float, causal: bool,
+             deterministic: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    be = get_backend()
+    varlen = cu_seqlens is not None
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
+    if not lse.is_contiguous():
+        lse = lse.contiguous()
+    delta = torch.empty_like(lse)
+    if varlen:
+        be.bwd_preprocess(dout, out, delta, cu_seqlens_q=cu_seqlens, max_seqlen_q=max_seqlen)
+    else:
+        be.bwd_preprocess(dout, out, delta)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
+    be.bwd(dout, q, k, v, lse, delta, softmax_scale=softmax_scale, causal=causal, dq=dq, dk=dk, dv=dv,
+           deterministic=deterministic, **_vl(cu_seqlens, max_seqlen))
+    return dq, dk, dv
+
+
+@attn_bwd.register_fake
+def _attn_bwd_fake(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale, causal, deterministic):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty(k.shape, dtype=k.dtype, device=k.device),
+            torch.empty(v.shape, dtype=v.dtype, device=v.device))
+
+
+def _setup_context(ctx, inputs, output):
+    q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, out, lse, cu_seqlens)
+    ctx.max_seqlen = max_seqlen
+    ctx.softmax_scale = softmax_scale
+    ctx.causal = causal
+
+
+def _backward(ctx, dout, dlse):
+    q, k, v, out, lse, cu_seqlens = ctx.saved_tensors
+    dq, dk, dv = torch.ops.rfa.attn_bwd(dout, q, k, v, out, lse, cu_seqlens, ctx.max_seqlen, ctx.softmax_scale,
+                                        ctx.causal, False)
+    return dq, dk, dv, None, None, None, None
+
+
+torch.library.register_autograd("rfa::attn_fwd", _backward, setup_context=_setup_context)
+
+
+def single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs):
+    """what every schedule of this package reduces to on a single-rank group, as traceable operators"""
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    out, lse = torch.ops.rfa.attn_fwd(q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal))
+    return (out, lse, None) if return_attn_probs else out

@@ -301,3 +301,25 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
         _check(f"spill={spill}.dq_acc", dqa - 3.0, rdq, 1e-2, 2e-2)
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
     _check("dq spill vs recompute", res[True][0], res[False][0].float(), 1e-2, 2e-2)
+
+
+def test_torch_compile_fullgraph_on_gpu(single_rank_group):
+    """the custom operators rfa::attn_fwd / rfa::attn_bwd run the HIP kernels under torch.compile(fullgraph=True)
+    (no graph break) and reproduce the eager path bit for bit (test/test.sh:23-25 of the reference)."""
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+
+    backend.set_backend(None)
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(1, 640, 3, 4, 128, generator=g).to(BF).to(dev)
+    do = torch.randn(1, 640, 4, 128, generator=g).to(BF).to(dev)
+    torch._dynamo.reset()
+    xe = qkv.clone().requires_grad_(True)
+    oe, le, _ = R.zigzag_ring_flash_attn_qkvpacked_func(xe, causal=True, return_attn_probs=True)
+    oe.backward(do)
+    xc = qkv.clone().requires_grad_(True)
+    oc, lc, _ = torch.compile(R.zigzag_ring_flash_attn_qkvpacked_func, fullgraph=True)(xc, causal=True, return_attn_probs=True)
+    oc.backward(do)
+    assert torch.equal(oc, oe) and torch.equal(lc, le) and torch.equal(xc.grad, xe.grad)
+    torch._dynamo.reset()

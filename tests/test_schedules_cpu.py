@@ -88,9 +88,11 @@ def test_ringcomm_guards(single_rank_group):
         c.commit()
 
 
-def test_torch_compile_tolerance(single_rank_group):
-    """the reference runs every test a second time under torch.compile (test/test.sh:23-25); the
-    public callables must survive being wrapped (they are opaque to dynamo and run eagerly)."""
+def test_torch_compile_captures_custom_ops(single_rank_group):
+    """the reference runs every test a second time under torch.compile (test/test.sh:23-25).  On a single-rank
+    group the public functions lower to the registered custom operators rfa::attn_fwd / rfa::attn_bwd (fake
+    kernels + autograd formula, ring_flash_attn/_ops.py): `fullgraph=True` proves there is NO graph break, the
+    captured graph contains the operator, and results / gradients equal the eager path bit for bit."""
     import torch
     import ring_flash_attn as R
     from ring_flash_attn import backend
@@ -100,15 +102,48 @@ def test_torch_compile_tolerance(single_rank_group):
     try:
         g = torch.Generator().manual_seed(3)
         qkv = torch.randn(1, 32, 3, 2, 16, generator=g).to(torch.bfloat16)
-        eager = R.zigzag_ring_flash_attn_qkvpacked_func(qkv, causal=True)
+        do = torch.randn(1, 32, 2, 16, generator=g).to(torch.bfloat16)
+        torch._dynamo.reset()
         torch._dynamo.config.capture_scalar_outputs = True
-        compiled = torch.compile(R.zigzag_ring_flash_attn_qkvpacked_func)
-        x = qkv.clone().requires_grad_(True)
-        out = compiled(x, causal=True)
-        out.sum().backward()
-        assert torch.equal(out, eager) and x.grad is not None and x.grad.shape == qkv.shape
+        graphs = []
+
+        def spy(gm, example_inputs):
+            graphs.append(gm)
+            return gm.forward
+
+        for fn in (R.zigzag_ring_flash_attn_qkvpacked_func, R.ring_flash_attn_qkvpacked_func,
+                   R.stripe_flash_attn_qkvpacked_func):
+            xe = qkv.clone().requires_grad_(True)
+            eager, lse_e, _ = fn(xe, causal=True, return_attn_probs=True)
+            eager.backward(do)
+            xc = qkv.clone().requires_grad_(True)
+            out, lse, none = torch.compile(fn, backend=spy, fullgraph=True)(xc, causal=True, return_attn_probs=True)
+            out.backward(do)
+            assert none is None and torch.equal(out, eager) and torch.equal(lse, lse_e)
+            assert torch.equal(xc.grad, xe.grad)
+        assert graphs and all(any("rfa.attn_fwd" in str(n.target) for n in gm.graph.nodes) for gm in graphs)
+
+        # packed varlen form, dense kv-packed form with GQA, and a real inductor compile of a caller
+        cu = torch.tensor([0, 12, 32], dtype=torch.int32)
+        pv = qkv[0].clone().requires_grad_(True)
+        ev = R.zigzag_ring_flash_attn_varlen_qkvpacked_func(pv, cu, 20, causal=True)
+        cv = torch.compile(R.zigzag_ring_flash_attn_varlen_qkvpacked_func, backend=spy, fullgraph=True)(pv, cu, 20, causal=True)
+        assert torch.equal(ev, cv)
+
+        def model(q, kv):
+            return (R.ring_flash_attn_kvpacked_func(q * 0.5, kv, causal=False) * 2.0).float().sum()
+
+        q = torch.randn(1, 24, 4, 16, generator=g).to(torch.bfloat16)
+        kv = torch.randn(1, 24, 2, 2, 16, generator=g).to(torch.bfloat16)
+        qe, kve = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        model(qe, kve).backward()
+        qc, kvc = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+        torch.compile(model, fullgraph=True)(qc, kvc).backward()
+        assert (qc.grad.float() - qe.grad.float()).abs().max() <= 1e-2 * qe.grad.float().abs().max()
+        assert (kvc.grad.float() - kve.grad.float()).abs().max() <= 1e-2 * kve.grad.float().abs().max()
     finally:
         backend.set_backend(None)
+        torch._dynamo.reset()
 
 
 def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
