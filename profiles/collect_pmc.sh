@@ -1,16 +1,29 @@
 #!/bin/bash
-# Collect the PMC evidence under profiles/ (run on the GPU box through gpurun; separate passes, counters
-# only together with --kernel-trace, as MI355X_MICROARCH.md prescribes).  Output: gpurun_out/pmc/<pass>/...
-# summarise with:  python profiles/summarize_rocpd.py gpurun_out/pmc/<pass>/*/*_results.db
+# Collect the rocprofv3 evidence under profiles/ (run on the GPU box through gpurun):
+#   pass kt     --kernel-trace --stats over the exact bench.py command line the driver runs
+#   pass sq/lds/fetch/write   separate --pmc passes (counters only together with --kernel-trace, as
+#               MI355X_MICROARCH.md prescribes; FETCH_SIZE and WRITE_SIZE cannot share a pass)
+# over the PRODUCT path (python bench.py: 5-GEMM backward with the dS spill), a few steps each.
+# Output: gpurun_out/prof/<pass>/...; summaries: gpurun_out/prof/<tag>_*.txt (+ <tag>_traffic.json, which
+# carries the content hash of the kernel sources it was measured on — bench.py refuses a stale one).
+#   usage: bash profiles/collect_pmc.sh r02        (then copy gpurun_out/prof/r02_* into profiles/)
 set -u
-cd /tmp && export TMPDIR=/tmp
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-B="$R/tests/native/selftest --perf-only"
-OUT=$R/gpurun_out/pmc
+cd /tmp && export TMPDIR=/tmp
+OUT=$R/gpurun_out/prof
 mkdir -p $OUT
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name -- $B > $OUT/$name.log 2>&1; }
+BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
+SHORT="python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown"
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name -- $SHORT > $OUT/$name.log 2>&1; }
 run sq    SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16
 run lds   SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VALU GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-ls -R $OUT | head -40
+cd $R
+{ echo "# rocprofv3 --kernel-trace --stats -- $BENCH"; python profiles/summarize_rocpd.py $(find $OUT/kt -name "*_results.db" | head -1); grep '^{' $OUT/kt.log | tail -1; } > $OUT/${TAG}_bench_kernel_trace_stats.txt 2>&1
+{ echo "# separate rocprofv3 --pmc passes over: $SHORT   (per-dispatch averages per counter instance)";
+  for p in sq lds fetch write; do echo "== pass: $p"; python profiles/summarize_rocpd.py $(find $OUT/$p -name "*_results.db" | head -1) --pmc | sed -n '/per-dispatch counter averages/,$p' | tail -n +2; done; } > $OUT/${TAG}_pmc_counters.txt 2>&1
+python profiles/make_traffic.py $OUT/${TAG}_pmc_counters.txt $OUT/${TAG}_traffic.json
+tail -5 $OUT/${TAG}_bench_kernel_trace_stats.txt; cat $OUT/${TAG}_traffic.json

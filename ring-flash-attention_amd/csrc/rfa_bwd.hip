@@ -53,13 +53,20 @@ constexpr int kDqWaves = 8;
 constexpr int kDqThreads = kDqWaves * 64;
 constexpr int kDqRows = kDqWaves * 32;          // 256 query rows / workgroup
 constexpr int kDqKV = 64;
-constexpr int kDqTileBytes = kDqKV * kRowBytes; // 16 KiB
-constexpr int kDqSmem = 4 * kDqTileBytes;       // K[2] V[2]
+template <int kD> constexpr int dq_smem() { return 4 * kDqKV * kD * 2; }   // K[2] V[2]
 
-template <typename T, bool kFullD>
+// kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging), else zero padded (register staging)
+template <typename T, int kD, bool kFullD>
 __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
+  typedef HeadGeo<kD> Geo;
+  constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
+  constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
+  constexpr int kDqTileBytes = kDqKV * kRowBytes;            // 16 KiB (8 KiB at kD = 64)
+  constexpr int kShare = kDqTileBytes / 1024 / kDqWaves;     // 1 KiB DMA pieces per wave and tile
+  constexpr int kChunks = kD / 8;
+  constexpr int kRowsPerPass = kDqThreads / kChunks;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,9 +103,9 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
   const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
 
-  vec8<T> qf[8], dof[8];
+  vec8<T> qf[kNK], dof[kNK];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
+  for (int kk = 0; kk < kNK; ++kk) {
     const int d0 = 16 * kk + 8 * g;
     qf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
     dof[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
@@ -111,8 +118,8 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   if (p.causal && qend + off < kmax) kmax = qend + off;
   const int ntiles = kmax > 0 ? (kmax + kDqKV - 1) / kDqKV : 0;
 
-  const int sc = tid & 15;
-  const int sr = tid >> 4;
+  const int sc = tid % kChunks;
+  const int sr = tid / kChunks;
   const bool sd_ok = kFullD || sc * 8 < p.D;
   // K/V tiles are fetched with raw buffer loads (fixed per-thread byte offsets, the tile advance lives in
   // the scalar descriptor, rows past the end of the sequence read as zero).  With D == 128 they go
@@ -121,15 +128,12 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   // chunk L%16 and must FETCH the logical chunk the swizzle puts there.  D < 128 needs the chunks
   // beyond D zeroed and takes the register path.
   constexpr bool kDma = kFullD;
-  vec8<T> kreg[2], vreg[2];
-  int voff_k[2], voff_v[2];
+  vec8<T> kreg[kShare], vreg[kShare];
+  int voff_k[kShare], voff_v[kShare];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = sr + 32 * i, chunk = sc;
-    if (kDma) {
-      row = 4 * (wave + 8 * i) + (lane >> 4);
-      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
-    }
+  for (int i = 0; i < kShare; ++i) {
+    int row = sr + kRowsPerPass * i, chunk = sc;
+    if (kDma) dma_lane_src<kD>(wave + kDqWaves * i, lane, row, chunk);
     voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
     voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
   }
@@ -144,9 +148,9 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
     const dma_rsrc_t dk = make_dma_rsrc(kbase + (int64_t)j * kDqKV * p.k_st.row, nk);
     const dma_rsrc_t dv = make_dma_rsrc(vbase + (int64_t)j * kDqKV * p.v_st.row, nv);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kShare; ++i) {
       if (kDma) {
-        const int dst = lds_addr(smem) + kStage * kDqTileBytes + (wave + 8 * i) * 1024;
+        const int dst = lds_addr(smem) + kStage * kDqTileBytes + (wave + kDqWaves * i) * 1024;
         dma_load128(dk, dst, voff_k[i]);
         dma_load128(dv, dst + 2 * kDqTileBytes, voff_v[i]);
       } else {
@@ -163,35 +167,37 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
     constexpr int kStage = decltype(stage)::value;
     if (!kDma) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int o = tile_off(sr + 32 * i, sc);
+      for (int i = 0; i < kShare; ++i) {
+        const int o = tile_off_d<kD>(sr + kRowsPerPass * i, sc);
         lds_write128<T>(smem + kStage * kDqTileBytes + o, kreg[i]);
         lds_write128<T>(smem + (2 + kStage) * kDqTileBytes + o, vreg[i]);
       }
     }
   };
 
-  int koff[8];
+  int koff[kNK];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);
+  for (int kk = 0; kk < kNK; ++kk) {
+    koff[kk] = lds_addr(smem) + tile_off_d<kD>(l31, 2 * kk + g);
     pin_vgpr(koff[kk]);
   }
-  int toff[4][2];
+  // K^T transpose reads at rows 32 t + 16 ks + 8 hh + 4 g: row bits below the swizzle period are in the address
+  constexpr int kTK = Geo::kSwzRows / 16;
+  int toff[kNB][kTK][2];
 #pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
+  for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-    {
-      toff[dblk][hh] = lds_addr(smem) + (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
-                       tr_lane_off(lane, dblk, (2 * hh + g) & 3);
-      pin_vgpr(toff[dblk][hh]);
-    }
+    for (int kv = 0; kv < kTK; ++kv)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        toff[dblk][kv][hh] = lds_addr(smem) + tr_off_d<kD>(lane, dblk, 16 * kv + 8 * hh + 4 * g);
+        pin_vgpr(toff[dblk][kv][hh]);
+      }
 
   const float c = p.scale * kLog2e;
-  f32x16 dq[4];
+  f32x16 dq[kNB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
@@ -221,23 +227,24 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
         {
-          // S^T = K Q^T and dP^T = V dO^T as one 16-step pipeline, A fragments read kAhead ahead
+          // S^T = K Q^T and dP^T = V dO^T as one 2 kNK-step pipeline, A fragments read kAhead ahead
           constexpr int kAhead = RFA_DQ_AHEAD1;
-          vec8<T> a[16];
+          constexpr int kN = 2 * kNK;
+          vec8<T> a[kN];
           auto fa = [&](int i) {
-            return lds_read128<T>(lds_ptr(koff[i & 7]) + (i < 8 ? kbo : vbo) + t * 32 * kRowBytes);
+            return lds_read128<T>(lds_ptr(koff[i % kNK]) + (i < kNK ? kbo : vbo) + t * 32 * kRowBytes);
           };
 #pragma unroll
           for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
-            if (i < 8) s = mfma(a[i], qf[i], s);
-            else dp = mfma(a[i], dof[i - 8], dp);
+          for (int i = 0; i < kN; ++i) {
+            if (i + kAhead < kN) a[i + kAhead] = fa(i + kAhead);
+            if (i < kNK) s = mfma(a[i], qf[i], s);
+            else dp = mfma(a[i], dof[i - kNK], dp);
           }
           __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
-          for (int i = 0; i < 16 - kAhead; ++i) {
+          for (int i = 0; i < kN - kAhead; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
@@ -257,11 +264,14 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> dsb = pack8<T>(s, 8 * ks2);
+          constexpr int kPer = Geo::kSwzRows;
+          const int rows = 32 * t + 16 * ks2;
+          const int imm = kbo + (rows / kPer) * kPer * kRowBytes;
+          const int kv = (rows % kPer) / 16;
 #pragma unroll
-          for (int dblk = 0; dblk < 4; ++dblk) {
-            const int imm = kbo + (32 * t + 16 * ks2) * kRowBytes;
-            vec4<T> lo = lds_read_tr<T>(lds_ptr(toff[dblk][0]) + imm);
-            vec4<T> hi = lds_read_tr<T>(lds_ptr(toff[dblk][1]) + imm);
+          for (int dblk = 0; dblk < kNB; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(lds_ptr(toff[dblk][kv][0]) + imm);
+            vec4<T> hi = lds_read_tr<T>(lds_ptr(toff[dblk][kv][1]) + imm);
             dq[dblk] = mfma(concat<T>(lo, hi), dsb, dq[dblk]);
           }
         }
@@ -280,12 +290,12 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   const int64_t orow = qs.row0 + qrow;
   if (p.dq_acc == nullptr) {
     T* ob = (T*)p.dq + qbatch * p.dq_st.batch + orow * p.dq_st.row + (int64_t)h * p.dq_st.head;
-    store_rows16<T, kFullD>(ob, dq, p.scale, g, p.D, true);
+    store_rows16<T, kFullD, kNB>(ob, dq, p.scale, g, p.D, true);
   } else {
     float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + orow * p.dq_acc_st.row +
                 (int64_t)h * p.dq_acc_st.head;
 #pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
+    for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -322,15 +332,27 @@ constexpr int kKvWaves = 8;
 constexpr int kKvThreads = kKvWaves * 64;
 constexpr int kKvKeys = 128;                       // keys / workgroup
 constexpr int kKvQ = 64;                           // query rows per tile (2 sub-tiles of 32)
-constexpr int kKvTileBytes = kKvQ * kRowBytes;     // 16 KiB
 constexpr int kKvStatBytes = 2 * kKvQ * 4;         // lse[64] + delta[64] per stage
-constexpr int kKvKvBytes = kKvKeys * kRowBytes;    // 32 KiB per K / V tile
-constexpr int kKvSmem = 2 * kKvKvBytes + 4 * kKvTileBytes + 2 * kKvStatBytes;   // 129 KiB
+template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64)
+  return 2 * kKvKeys * kD * 2 + 4 * kKvQ * kD * 2 + 2 * kKvStatBytes;
+}
 
-template <typename T, bool kFullD, bool kSpill>
+// kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging) else zero padded (register staging);
+// kSpill: store dS for rfa_dqs.hip (kD = 128 only)
+template <typename T, int kD, bool kFullD, bool kSpill>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
+  static_assert(!kSpill || kD == 128, "the dS spill format is defined for head dim 128");
+  typedef HeadGeo<kD> Geo;
+  constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
+  constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
+  constexpr int kKvTileBytes = kKvQ * kRowBytes;             // 16 KiB (8 KiB at kD = 64)
+  constexpr int kKvKvBytes = kKvKeys * kRowBytes;            // 32 KiB (16 KiB) per K / V tile
+  constexpr int kChunks = kD / 8;
+  constexpr int kRowsPerPass = kKvThreads / kChunks;         // register staging: one chunk per thread and pass
+  constexpr int kPasses = kKvQ / kRowsPerPass;               // passes (= 1 KiB DMA pieces per wave) per Q / dO tile
+  constexpr int kTK = Geo::kSwzRows / 16;                    // k-steps of a transpose read that need their own address
   // LDS map (bytes): Q[2] 0 / 16K, dO[2] 32K / 48K, V 64K, stats[2] 128K.  Every address used in
   // the main loop is ONE per-lane VGPR (toggled between the two stages with an XOR once per tile) plus a
   // compile-time immediate — no vector address arithmetic beside the swizzle XORs.
@@ -383,33 +405,33 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int jt0 = qfirst / kKvQ;
   const int jt1 = (lq + kKvQ - 1) / kKvQ;     // exclusive
 
-  const int sc = tid & 15;
-  const int sr = tid >> 4;                    // 0..31
+  const int sc = tid % kChunks;
+  const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
   const bool sd_ok = kFullD || sc * 8 < p.D;
 
-  // ---- V rows of the workgroup go to LDS once (128 rows x 16 chunks = 4 chunks / thread); this wave's
-  // K rows stay in registers as the B operand of the S GEMM (32 registers)
+  // ---- V rows of the workgroup go to LDS once (128 rows x kChunks chunks); this wave's
+  // K rows stay in registers as the B operand of the S GEMM (4 kNK registers)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = sr + 32 * i;
+  for (int i = 0; i < kKvKeys / kRowsPerPass; ++i) {
+    const int row = sr + kRowsPerPass * i;
     int kr = kwg0 + row;
     kr = kr < lk ? kr : lk - 1;
     vec8<T> vc = zero8<T>();
     if (sd_ok) vc = *(const vec8<T>*)(vbase + (int64_t)kr * p.v_st.row + sc * 8);
-    lds_write128<T>(vtile + tile_off(row, sc), vc);
+    lds_write128<T>(vtile + tile_off_d<kD>(row, sc), vc);
   }
-  vec8<T> kwr[8];
+  vec8<T> kwr[kNK];
   {
     const int kr = krow < lk ? krow : lk - 1;
     const T* kp = kbase + (int64_t)kr * p.k_st.row;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
+    for (int kk = 0; kk < kNK; ++kk) {
       const int chunk = 2 * kk + g;
       kwr[kk] = (kFullD || chunk * 8 < p.D) ? *(const vec8<T>*)(kp + chunk * 8) : zero8<T>();
     }
   }
 
-  vec8<T> qreg[2], doreg[2];
+  vec8<T> qreg[kPasses], doreg[kPasses];
   float statreg = 0.f;
   // Row statistics are stored pre-multiplied (one multiply per staged value, done at LDS-write time when
   // the load has long landed): lse by -log2(e), so that P = exp2(S*c + stat) is a single FMA per element,
@@ -425,14 +447,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // that the swizzle puts there.  Otherwise (D < 128) the chunks beyond D have to be zeroed, which
   // needs the register path.
   constexpr bool kDma = kFullD;
-  int voff_q[2], voff_do[2];
+  int voff_q[kPasses], voff_do[kPasses];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = sr + 32 * i, chunk = sc;
-    if (kDma) {
-      row = 4 * (wave + 8 * i) + (lane >> 4);
-      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
-    }
+  for (int i = 0; i < kPasses; ++i) {
+    int row = sr + kRowsPerPass * i, chunk = sc;
+    if (kDma) dma_lane_src<kD>(wave + kKvWaves * i, lane, row, chunk);
     voff_q[i] = (row * (int)p.q_st.row + chunk * 8) * 2;
     voff_do[i] = (row * (int)p.dout_st.row + chunk * 8) * 2;
   }
@@ -465,9 +484,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     const dma_rsrc_t dq_ = make_dma_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
     const dma_rsrc_t ddo = make_dma_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kPasses; ++i) {
       if (kDma) {
-        const int dst = lds_addr(smem) + dma_stage + (wave + 8 * i) * 1024;
+        const int dst = lds_addr(smem) + dma_stage + (wave + kKvWaves * i) * 1024;
         dma_load128(dq_, dst, voff_q[i]);
         dma_load128(ddo, dst + kOffDo, voff_do[i]);
       } else {
@@ -487,14 +506,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     }
     dma_stage ^= kKvTileBytes;
   };
-  int wq = lds_addr(smem) + tile_off(sr, sc);                          // staging write address, stage 0 (row + 32: +8K immediate)
+  int wq = lds_addr(smem) + tile_off_d<kD>(sr, sc);                    // staging write address, stage 0 (further passes: immediate)
   int ws = lds_addr(smem) + kOffStat + tid * 4;
   auto write_tile = [&]() {
     if (!kDma) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        lds_write128<T>(lds_ptr(wq) + i * 32 * kRowBytes, qreg[i]);
-        lds_write128<T>(lds_ptr(wq) + i * 32 * kRowBytes + kOffDo, doreg[i]);
+      for (int i = 0; i < kPasses; ++i) {
+        lds_write128<T>(lds_ptr(wq) + i * kRowsPerPass * kRowBytes, qreg[i]);
+        lds_write128<T>(lds_ptr(wq) + i * kRowsPerPass * kRowBytes + kOffDo, doreg[i]);
       }
     }
     if (tid < 2 * kKvQ) *(__attribute__((address_space(3))) float*)lds_ptr(ws) = statreg * stat_scale;
@@ -505,15 +524,21 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // offset tables, which is what lets this kernel fit the 256-register budget of two waves per SIMD.
   // (XOR toggling / swizzling on absolute addresses: the dynamic LDS block starts 64 KiB-aligned — at 0 —
   //  because these kernels have no static LDS; checked at the top of the kernel)
-  int aq = lds_addr(smem) + tile_off(l31, g) + par * 32 * kRowBytes;                 // Q / dO sub-tile rows (stage toggled)
-  const int av = lds_addr(smem) + tile_off(l31, g) + kOffV + kbw * 32 * kRowBytes;   // this wave's V rows
-  int tq[2];                                                        // transpose-read bases (stage toggled)
+  int aq = lds_addr(smem) + tile_off_d<kD>(l31, g) + par * 32 * kRowBytes;                 // Q / dO sub-tile rows (stage toggled)
+  const int av = lds_addr(smem) + tile_off_d<kD>(l31, g) + kOffV + kbw * 32 * kRowBytes;   // this wave's V rows
+  // transpose-read bases (stage toggled), rows 32 par + 16 ks + 8 hh + 4 g: the row bits below the swizzle period
+  // (hh, g at kD = 128; ks, hh, g at kD = 64) are part of the address
+  int tq[kTK][2];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh)
-    tq[hh] = lds_addr(smem) + (32 * par + 8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes + tr_lane_off(lane, 0, (2 * hh + g) & 3);
+  for (int kv = 0; kv < kTK; ++kv)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      tq[kv][hh] = lds_addr(smem) + par * 32 * kRowBytes + tr_off_d<kD>(lane, 0, 16 * kv + 8 * hh + 4 * g);
+      pin_vgpr(tq[kv][hh]);
+    }
   int sa = lds_addr(smem) + kOffStat + (32 * par + 4 * g) * 4;                       // row statistics (stage toggled)
   int avp = av;
-  pin_vgpr(aq); pin_vgpr(avp); pin_vgpr(tq[0]); pin_vgpr(tq[1]); pin_vgpr(sa); pin_vgpr(wq); pin_vgpr(ws);
+  pin_vgpr(aq); pin_vgpr(avp); pin_vgpr(sa); pin_vgpr(wq); pin_vgpr(ws);
 
   // dS spill (rfa_dqs.hip): the two packed dS operands of every active (32 query x 32 key) block go to the
   // scratch block (b, h, qt = query row / 32, kb = key / 32) in the slot order that kernel reads back:
@@ -525,9 +550,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * 4 + kbw);
 
   const float c = p.scale * kLog2e;
-  f32x16 dk[4], dv[4];
+  f32x16 dk[kNB], dv[kNB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
 
@@ -559,29 +584,30 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       }
       {
         // dP - delta = dO V_w^T (+ init; V_w fragments from LDS) then S = Q K_w^T (K_w in registers):
-        // 16 MFMAs, LDS operands read kAhead steps ahead
+        // 2 kNK MFMAs, LDS operands read kAhead steps ahead
         constexpr int kAhead = RFA_KV_AHEAD;
-        vec8<T> a[16], w[8];
-        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + (i < 8 ? kOffDo : 0)); };
+        constexpr int kN = 2 * kNK;
+        vec8<T> a[kN], w[kNK];
+        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0)); };
         auto fw = [&](int i) { return lds_read128<T>(lds_ptr(avp ^ (i << 5))); };
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) { a[i] = fa(i); w[i] = fw(i); }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
-          if (i + kAhead < 8) w[i + kAhead] = fw(i + kAhead);
-          if (i < 8) dp = mfma(a[i], w[i], dp);
-          else s = mfma(a[i], kwr[i - 8], s);
+        for (int i = 0; i < kN; ++i) {
+          if (i + kAhead < kN) a[i + kAhead] = fa(i + kAhead);
+          if (i + kAhead < kNK) w[i + kAhead] = fw(i + kAhead);
+          if (i < kNK) dp = mfma(a[i], w[i], dp);
+          else s = mfma(a[i], kwr[i - kNK], s);
         }
 #if RFA_KV_PIN
         __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * kAhead, 0);
 #pragma unroll
-        for (int i = 0; i < 8 - kAhead; ++i) {
+        for (int i = 0; i < kNK - kAhead; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kNK; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -628,27 +654,30 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         };
         if (RFA_SPILL_PROBE != 2) spill();
         constexpr int kAhead = RFA_KV_AHEAD2;
-        vec8<T> a[16];
-        auto frag = [&](int i) {                       // i: [ks2][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk]
-          const int ks2 = i >> 3, which = (i >> 2) & 1, dblk = i & 3;
-          const int imm = (which ? 0 : kOffDo) + 16 * ks2 * kRowBytes;
-          vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[0] ^ (dblk << 6)) + imm);
-          vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[1] ^ (dblk << 6)) + imm);
+        constexpr int kN2 = 4 * kNB;                   // [ks2][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk]
+        vec8<T> a[kN2];
+        auto frag = [&](int i) {
+          const int ks2 = i / (2 * kNB), which = (i / kNB) & 1, dblk = i % kNB;
+          constexpr int kPer = Geo::kSwzRows;
+          const int kv = (16 * ks2 % kPer) / 16;
+          const int imm = (which ? 0 : kOffDo) + (16 * ks2 / kPer) * kPer * kRowBytes;
+          vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[kv][0] ^ (dblk << 6)) + imm);
+          vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[kv][1] ^ (dblk << 6)) + imm);
           return concat<T>(lo, hi);
         };
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) a[i] = frag(i);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16) a[i + kAhead] = frag(i + kAhead);
-          const int ks2 = i >> 3, which = (i >> 2) & 1, dblk = i & 3;
+        for (int i = 0; i < kN2; ++i) {
+          if (i + kAhead < kN2) a[i + kAhead] = frag(i + kAhead);
+          const int ks2 = i / (2 * kNB), which = (i / kNB) & 1, dblk = i % kNB;
           if (which == 0) dv[dblk] = mfma(a[i], ks2 ? pb1 : pb0, dv[dblk]);
           else dk[dblk] = mfma(a[i], ks2 ? ds1 : ds0, dk[dblk]);
         }
 #if RFA_KV_PIN
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 1);
 #pragma unroll
-        for (int i = 0; i < 16 - kAhead; ++i) {
+        for (int i = 0; i < kN2 - kAhead; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
           __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
         }
@@ -670,8 +699,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       --j;
     }
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
-    tq[0] ^= kKvTileBytes;
-    tq[1] ^= kKvTileBytes;
+#pragma unroll
+    for (int kv = 0; kv < kTK; ++kv) {
+      tq[kv][0] ^= kKvTileBytes;
+      tq[kv][1] ^= kKvTileBytes;
+    }
     sa ^= kKvStatBytes;
     wq ^= kKvTileBytes;
     ws ^= kKvStatBytes;
@@ -683,17 +715,18 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // tiles and the Q/dO buffers (128 KiB, contiguous) are dead by now and take the 2 x 64 KiB of partials.
   {
     float* xbuf = (float*)smem_raw;                    // generic pointer into LDS
-    const int slot = (par == 1 ? 0 : 16384) + kbw * 4096;  // floats: 4 kb x 4096 per tensor (2 x 64 KiB)
-    const f32x16(&mine)[4] = (par == 1) ? dk : dv;
+    constexpr int kXW = kNB * 1024;                    // floats per key block and tensor (4 kb per tensor: 2 x 64 KiB at kD = 128)
+    const int slot = (par == 1 ? 0 : 4 * kXW) + kbw * kXW;
+    const f32x16(&mine)[kNB] = (par == 1) ? dk : dv;
 #pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
+    for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xbuf[slot + (dblk * 16 + r) * 64 + lane] = mine[dblk][r];
     __syncthreads();
-    const int rslot = (par == 0 ? 0 : 16384) + kbw * 4096;  // parity 0 finishes dK, parity 1 finishes dV
-    f32x16(&fin)[4] = (par == 0) ? dk : dv;
+    const int rslot = (par == 0 ? 0 : 4 * kXW) + kbw * kXW;  // parity 0 finishes dK, parity 1 finishes dV
+    f32x16(&fin)[kNB] = (par == 0) ? dk : dv;
 #pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
+    for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) fin[dblk][r] += xbuf[rslot + (dblk * 16 + r) * 64 + lane];
   }
@@ -703,14 +736,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   if (p.kv_f32) {
     // fp32 store straight into the caller's accumulator slot (overwrite): lane (key, g) holds, per
     // (dblk, jj), the 4 consecutive columns 32 dblk + 8 jj + 4 g .. +3
-    const f32x16(&fin)[4] = (par == 0) ? dk : dv;
+    const f32x16(&fin)[kNB] = (par == 0) ? dk : dv;
     const float sc_ = (par == 0) ? p.scale : 1.f;
     const int64_t sb = (par == 0) ? p.dk_st.batch : p.dv_st.batch;
     const int64_t sr_ = (par == 0) ? p.dk_st.row : p.dv_st.row;
     const int64_t sh = (par == 0) ? p.dk_st.head : p.dv_st.head;
     float* ob = (float*)((par == 0) ? p.dk : p.dv) + kbatch * sb + orow * sr_ + (int64_t)hk * sh;
 #pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)
+    for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -725,44 +758,52 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   }
   if (par == 0) {
     T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)hk * p.dk_st.head;
-    store_rows16<T, kFullD>(dkb, dk, p.scale, g, p.D, true);
+    store_rows16<T, kFullD, kNB>(dkb, dk, p.scale, g, p.D, true);
   } else {
     T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)hk * p.dv_st.head;
-    store_rows16<T, kFullD>(dvb, dv, 1.f, g, p.D, true);
+    store_rows16<T, kFullD, kNB>(dvb, dv, 1.f, g, p.D, true);
   }
 }
 
-template <typename T, bool kFullD>
+template <typename T, int kD, bool kFullD>
 static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kFullD>, kDqSmem, attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kD, kFullD>, dq_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dq_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kDqThreads), kDqSmem, stream, p);
+  hipLaunchKernelGGL((dq_kernel<T, kD, kFullD>), dim3((unsigned)nblocks), dim3(kDqThreads), dq_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, bool kFullD, bool kSpill>
+template <typename T, int kD, bool kFullD, bool kSpill>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kFullD, kSpill>, kKvSmem, attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill>, kv_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B;      // one workgroup per (key block, K/V head)
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kFullD, kSpill>), dim3((unsigned)nblocks), dim3(kKvThreads), kKvSmem, stream, p);
+  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
+template <typename T>
+static int launch_dq_d(const BwdParams& p, hipStream_t stream) {
+  if (p.D == 128) return launch_dq_t<T, 128, true>(p, stream);
+  if (p.D > 64) return launch_dq_t<T, 128, false>(p, stream);
+  if (p.D == 64) return launch_dq_t<T, 64, true>(p, stream);
+  return launch_dq_t<T, 64, false>(p, stream);
+}
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
-  const bool full = p.D == kHeadDim;
-  if (dtype == 0) return full ? launch_dq_t<bf16_t, true>(p, stream) : launch_dq_t<bf16_t, false>(p, stream);
-  return full ? launch_dq_t<f16_t, true>(p, stream) : launch_dq_t<f16_t, false>(p, stream);
+  return dtype == 0 ? launch_dq_d<bf16_t>(p, stream) : launch_dq_d<f16_t>(p, stream);
+}
+template <typename T>
+static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
+  if (p.D == 128) return p.ds != nullptr ? launch_dkdv_t<T, 128, true, true>(p, stream) : launch_dkdv_t<T, 128, true, false>(p, stream);
+  if (p.D > 64) return launch_dkdv_t<T, 128, false, false>(p, stream);
+  if (p.D == 64) return launch_dkdv_t<T, 64, true, false>(p, stream);
+  return launch_dkdv_t<T, 64, false, false>(p, stream);
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
-  const bool full = p.D == kHeadDim;
-  if (full && p.ds != nullptr)
-    return dtype == 0 ? launch_dkdv_t<bf16_t, true, true>(p, stream) : launch_dkdv_t<f16_t, true, true>(p, stream);
-  if (dtype == 0) return full ? launch_dkdv_t<bf16_t, true, false>(p, stream) : launch_dkdv_t<bf16_t, false, false>(p, stream);
-  return full ? launch_dkdv_t<f16_t, true, false>(p, stream) : launch_dkdv_t<f16_t, false, false>(p, stream);
+  return dtype == 0 ? launch_dkdv_d<bf16_t>(p, stream) : launch_dkdv_d<f16_t>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
 int bwd_dkdv_keys_per_block() { return kKvKeys; }

@@ -83,6 +83,51 @@ __device__ __forceinline__ vec4<T> lds_read_tr(lds_t* p) {
   return __builtin_bit_cast(vec4<T>, r);
 }
 
+// ---- head-dim geometry -------------------------------------------------------------------------------
+// The attention kernels are compiled for kD = 128 and kD = 64 (runtime D <= kD, zero padded).  LDS tiles always
+// use 256-byte PHYSICAL rows so that the one swizzle above serves both: with kD = 64 a physical row holds two
+// logical rows (logical row r, 16-byte chunk c in 0..7 -> physical row r >> 1, chunk ((r & 1) << 3) | c).  Both
+// conflict properties carry over: a 16-lane ds_read_b128 group (16 distinct rows, one chunk) still sees 16
+// distinct 16-byte slots, and the 4-row x 64-byte footprint of a transpose read still covers 256 distinct bytes.
+template <int kD>
+struct HeadGeo {
+  static_assert(kD == 64 || kD == 128, "compiled head dims");
+  static constexpr int kRowBytes = kD * 2;               // logical row
+  static constexpr int kKSteps = kD / 16;                // 16-wide k-steps of a contraction over d
+  static constexpr int kDBlocks = kD / 32;               // 32-wide blocks of d (accumulator tiles)
+  static constexpr int kSwzRows = kD == 128 ? 16 : 32;   // logical rows after which the swizzle repeats:
+                                                         // tile_off_d(r + kSwzRows, c) = tile_off_d(r, c) + kSwzRows * kRowBytes
+};
+template <int kD>
+__device__ __forceinline__ int tile_off_d(int row, int chunk) {
+  if (kD == 128) return row * 256 + ((chunk ^ swz(row)) << 4);
+  const int prow = row >> 1, c = ((row & 1) << 3) | chunk;
+  return prow * 256 + ((c ^ swz(prow)) << 4);
+}
+// (logical row, chunk) that lane `lane` of the LDS-DMA instruction filling physical rows 4 piece .. 4 piece + 3
+// (1 KiB, lane-linear destination) has to fetch so that the tile ends up swizzled
+template <int kD>
+__device__ __forceinline__ void dma_lane_src(int piece, int lane, int& row, int& chunk) {
+  const int prow = 4 * piece + (lane >> 4);
+  const int c = (lane & 15) ^ swz(prow);
+  if (kD == 128) {
+    row = prow;
+    chunk = c;
+  } else {
+    row = 2 * prow + (c >> 3);
+    chunk = c & 7;
+  }
+}
+// Transpose-read address (byte offset inside a tile) with which lane `lane` takes part in reading rows
+// rb .. rb+3 (rb % 4 == 0) of d block dblk: MFMA A-operand lane (m = 32 dblk + lane & 31) receives
+// tile[rb + j][m], j = 0..3.  Valid for rb + any multiple of kSwzRows by adding rows * kRowBytes.
+template <int kD>
+__device__ __forceinline__ int tr_off_d(int lane, int dblk, int rb) {
+  const int i = lane & 15, sub = (lane >> 4) & 1;
+  const int chunk = 4 * dblk + 2 * sub + ((i & 3) >> 1);
+  return tile_off_d<kD>(rb + (i >> 2), chunk) + ((i & 1) << 3);
+}
+
 template <typename T>
 __device__ __forceinline__ vec8<T> concat(vec4<T> a, vec4<T> b) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -164,11 +209,11 @@ __device__ __forceinline__ void wait_all_vmem() { __builtin_amdgcn_s_waitcnt(0x0
 // consecutive columns.  One v_permlane32_swap per dword exchanges "upper half's group jj" with "lower
 // half's group jj+1", after which each lane owns 8 consecutive columns = ONE 16-byte store (lower
 // half: group jj, upper half: group jj+1) instead of two 8-byte stores.  All 64 lanes must call it.
-template <typename T, bool kFullD>
-__device__ __forceinline__ void store_rows16(T* row_ptr, const f32x16 (&acc)[4], float scale, int g, int D,
+template <typename T, bool kFullD, int kNB = 4>
+__device__ __forceinline__ void store_rows16(T* row_ptr, const f32x16 (&acc)[kNB], float scale, int g, int D,
                                              bool row_ok) {
 #pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
+  for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       f32x4 x0, x1;

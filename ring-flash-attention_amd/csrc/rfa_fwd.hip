@@ -34,22 +34,28 @@ namespace rfa {
 #define RFA_FWD_WAVES 8      // waves per workgroup (32 q rows each); 4 -> two independent workgroups per CU
 #endif
 constexpr int kFwdWaves = RFA_FWD_WAVES;
-constexpr int kFwdShare = 16 / kFwdWaves;   // 4-row groups of a 64-row tile staged by each wave
 constexpr int kFwdThreads = kFwdWaves * 64;
 constexpr int kFwdQRows = kFwdWaves * 32;   // query rows per workgroup
 constexpr int kFwdKV = 64;                  // keys per tile
-constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB
 #ifndef RFA_FWD_STAGES
 #define RFA_FWD_STAGES 2     // LDS ring depth: tile j+STAGES-1 is in flight (DMA) while tile j is computed
 #endif
 constexpr int kFwdStages = RFA_FWD_STAGES;
-constexpr int kFwdSmem = 2 * kFwdStages * kFwdTileBytes;    // K[stages] + V[stages] (96 KiB at 3)
+template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * kD * 2; }   // K[stages] + V[stages]
 
-template <typename T, bool kFullD>
+// kD: compiled head dim (128 or 64: half the MFMAs, half the LDS bytes per tile); kFullD: D == kD (LDS-DMA
+// staging, no conditional loads), otherwise D < kD is zero padded through the register staging path
+template <typename T, int kD, bool kFullD>
 __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   // LDS map: K stages at [0, stages*tile), V stages behind them
+  typedef HeadGeo<kD> Geo;
+  constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
+  constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
+  constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB (8 KiB at kD = 64)
+  constexpr int kFwdShare = kFwdTileBytes / 1024 / kFwdWaves;   // 1 KiB DMA pieces (4 physical rows) per wave
+  constexpr int kChunks = kD / 8;                            // 16-byte chunks per logical row
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
                    (int64_t)hk * p.v_st.head;
 
   // ---- Q fragment (B operand of S^T = K Q^T): lane (q = l31, g) holds d = 16kk + 8g .. +7
-  vec8<T> qf[8];
+  vec8<T> qf[kNK];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
+  for (int kk = 0; kk < kNK; ++kk) {
     const int d0 = 16 * kk + 8 * g;
     qf[kk] = (kFullD || d0 < p.D) ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
   }
@@ -110,18 +116,16 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   // the logical chunk the swizzle puts there.  D < 128 needs the chunks beyond D zeroed and goes
   // global -> registers -> LDS (issue early / write late).
   constexpr bool kDma = kFullD;
-  const int sc = tid & 15;
-  const int sr = tid >> 4;
+  constexpr int kRowsPerPass = kFwdThreads / kChunks;      // register path: one 16-byte chunk per thread and pass
+  const int sc = tid % kChunks;
+  const int sr = tid / kChunks;
   const bool sd_ok = kFullD || sc * 8 < p.D;
   vec8<T> kreg[kFwdShare], vreg[kFwdShare];
   int voff_k[kFwdShare], voff_v[kFwdShare];
 #pragma unroll
   for (int i = 0; i < kFwdShare; ++i) {
-    int row = sr + 4 * kFwdWaves * i, chunk = sc;
-    if (kDma) {
-      row = 4 * (wave + kFwdWaves * i) + (lane >> 4);
-      chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
-    }
+    int row = sr + kRowsPerPass * i, chunk = sc;
+    if (kDma) dma_lane_src<kD>(wave + kFwdWaves * i, lane, row, chunk);
     voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
     voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
   }
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     if (!kDma) {
 #pragma unroll
       for (int i = 0; i < kFwdShare; ++i) {
-        const int o = tile_off(sr + 4 * kFwdWaves * i, sc);
+        const int o = tile_off_d<kD>(sr + kRowsPerPass * i, sc);
         lds_write128<T>(smem + kStage * kFwdTileBytes + o, kreg[i]);
         lds_write128<T>(smem + (kFwdStages + kStage) * kFwdTileBytes + o, vreg[i]);
       }
@@ -168,29 +172,33 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
   // ---- per-lane LDS addresses (absolute, finished once; the loop only adds instruction immediates)
   // K fragment (A operand): row = 32t + l31, chunk = 2kk + g
-  int koff[8];
+  int koff[kNK];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);   // + t*32*256
+  for (int kk = 0; kk < kNK; ++kk) {
+    koff[kk] = lds_addr(smem) + tile_off_d<kD>(l31, 2 * kk + g);   // + t * 32 rows
     pin_vgpr(koff[kk]);
   }
-  // V^T fragment via transpose read: rows rb = 32t + 16ks + 8hh + 4g (+ i>>2)
-  int voff[4][2];
+  // V^T fragment via transpose read: rows rb = 32t + 16ks + 8hh + 4g (+ i>>2).  The row bits below the swizzle
+  // period (16 rows at kD = 128: hh, g; 32 rows at kD = 64: ks, hh, g) are part of the per-lane address, the
+  // rest is an instruction immediate.
+  constexpr int kVK = Geo::kSwzRows / 16;                  // k-steps that need their own address
+  int voff[kNB][kVK][2];
 #pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
+  for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      voff[dblk][hh] = lds_addr(smem) + (8 * hh + 4 * g + ((lane & 15) >> 2)) * kRowBytes +
-                       tr_lane_off(lane, dblk, (2 * hh + g) & 3);
-      pin_vgpr(voff[dblk][hh]);
-    }
+    for (int kv = 0; kv < kVK; ++kv)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        voff[dblk][kv][hh] = lds_addr(smem) + tr_off_d<kD>(lane, dblk, 16 * kv + 8 * hh + 4 * g);
+        pin_vgpr(voff[dblk][kv][hh]);
+      }
 
   const float c = p.scale * kLog2e;
   float m = -INFINITY;
   float lsum = 0.f;
-  f32x16 o[4];
+  f32x16 o[kNB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
@@ -228,21 +236,22 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
       {
-        // 16 K fragments (2 sub-tiles x 8 k-steps), read kAhead ahead of their MFMA
+        // 2 kNK K fragments (2 sub-tiles x kNK k-steps), read kAhead ahead of their MFMA
         constexpr int kAhead = RFA_FWD_AHEAD;
-        vec8<T> a[16];
-        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + kbo + (i >> 3) * 32 * kRowBytes); };
+        constexpr int kN = 2 * kNK;
+        vec8<T> a[kN];
+        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(koff[i % kNK]) + kbo + (i / kNK) * 32 * kRowBytes); };
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i + kAhead < 16) a[i + kAhead] = fa(i + kAhead);
-          s[i >> 3] = mfma(a[i], qf[i & 7], s[i >> 3]);
+        for (int i = 0; i < kN; ++i) {
+          if (i + kAhead < kN) a[i + kAhead] = fa(i + kAhead);
+          s[i / kNK] = mfma(a[i], qf[i % kNK], s[i / kNK]);
         }
         // pin the issue order: kAhead reads, then read/MFMA pairs, then the MFMA tail
         __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
 #pragma unroll
-        for (int i = 0; i < 16 - kAhead; ++i) {
+        for (int i = 0; i < kN - kAhead; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         m = mnew;
         lsum *= alpha;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < kNB; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
@@ -301,11 +310,14 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> pb = pack8<T>(s[t], 8 * ks2);
-          const int imm = vbo + (32 * t + 16 * ks2) * kRowBytes;
+          constexpr int kPer = Geo::kSwzRows;                       // rows covered by the address table
+          const int rows = 32 * t + 16 * ks2;
+          const int imm = vbo + (rows / kPer) * kPer * kRowBytes;
+          const int kv = (rows % kPer) / 16;
 #pragma unroll
-          for (int dblk = 0; dblk < 4; ++dblk) {
-            vec4<T> lo = lds_read_tr<T>(lds_ptr(voff[dblk][0]) + imm);
-            vec4<T> hi = lds_read_tr<T>(lds_ptr(voff[dblk][1]) + imm);
+          for (int dblk = 0; dblk < kNB; ++dblk) {
+            vec4<T> lo = lds_read_tr<T>(lds_ptr(voff[dblk][kv][0]) + imm);
+            vec4<T> hi = lds_read_tr<T>(lds_ptr(voff[dblk][kv][1]) + imm);
             o[dblk] = mfma(concat<T>(lo, hi), pb, o[dblk]);
           }
         }
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
   if (p.out_acc == nullptr) {
     T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
-    store_rows16<T, kFullD>(ob, o, inv, g, p.D, true);
+    store_rows16<T, kFullD, kNB>(ob, o, inv, g, p.D, true);
     if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
   } else {
     float* ab = p.out_acc + qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row +
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     float* lp = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
     if (p.acc_init) {
 #pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk)
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       const float wb = eb / den * inv;
       const float lnew = mx + __logf(den);
 #pragma unroll
-      for (int dblk = 0; dblk < 4; ++dblk)
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -388,20 +400,26 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   }
 }
 
-template <typename T, bool kFullD>
+template <typename T, int kD, bool kFullD>
 static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kFullD>, kFwdSmem, attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD>, fwd_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((fwd_kernel<T, kFullD>), dim3((unsigned)nblocks), dim3(kFwdThreads), kFwdSmem, stream, p);
+  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
+template <typename T>
+static int launch_fwd_d(const FwdParams& p, hipStream_t stream) {
+  if (p.D == 128) return launch_fwd_t<T, 128, true>(p, stream);
+  if (p.D > 64) return launch_fwd_t<T, 128, false>(p, stream);
+  if (p.D == 64) return launch_fwd_t<T, 64, true>(p, stream);
+  return launch_fwd_t<T, 64, false>(p, stream);
+}
+
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
-  const bool full = p.D == kHeadDim;
-  if (dtype == 0) return full ? launch_fwd_t<bf16_t, true>(p, stream) : launch_fwd_t<bf16_t, false>(p, stream);
-  return full ? launch_fwd_t<f16_t, true>(p, stream) : launch_fwd_t<f16_t, false>(p, stream);
+  return dtype == 0 ? launch_fwd_d<bf16_t>(p, stream) : launch_fwd_d<f16_t>(p, stream);
 }
 
 int fwd_qrows_per_block() { return kFwdQRows; }

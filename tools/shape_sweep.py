@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-GPU kernel throughput over shapes (world size 1 path: rfa_fwd / rfa_bwd through the C ABI),
 to see how the headline-tuned kernels behave elsewhere.  Algorithmic FLOPs: fwd 4*B*H*Sq*Sk*D (/2 causal),
-bwd 2.5x.   usage: python tools/shape_sweep.py"""
+bwd 2.5x.   usage: python tools/shape_sweep.py [B,S,H,Hk,D,causal ...]   (no arguments: the standard table)"""
 import os
 import sys
 
@@ -52,6 +52,11 @@ def run(B, S, H, Hk, D, causal, dtype=torch.bfloat16):
 
 print("| B | S | H/Hk | D | mask | fwd ms | fwd TFLOP/s | bwd ms | bwd TFLOP/s |")
 print("|---|---|---|---|---|---|---|---|---|")
+if len(sys.argv) > 1:
+    for spec in sys.argv[1:]:
+        B, S, H, Hk, D, causal = (int(x) for x in spec.split(","))
+        run(B, S, H, Hk, D, bool(causal))
+    sys.exit(0)
 for S in (1024, 2048, 4096, 8192, 16384, 32768):
     run(max(1, 8192 // S), S, 32, 8, 128, True)
 run(1, 8192, 32, 32, 128, True)
