@@ -105,6 +105,13 @@ typedef struct {
   float softmax_scale;
   int32_t causal;
   int32_t dtype; /* rfa_dtype */
+  /* Local (sliding window) attention, flash_attn semantics (window_size_left / window_size_right of
+   * _flash_attn_forward, forwarded by /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:147 and
+   * adapters/hf_adapter.py:121-128): query i sees keys j with
+   *     i + (len_k - len_q) - window_left <= j <= i + (len_k - len_q) + window_right ;
+   * a negative value leaves that side unbounded; `causal` forces window_right = 0.  Only honoured when
+   * `window` is non-zero, so that a zero-initialised struct means "no window". */
+  int32_t window, window_left, window_right;
 } rfa_fwd_args;
 
 typedef struct {
@@ -158,6 +165,7 @@ typedef struct {
    * only meaningful between the two kernels of one call (or between a RFA_BWD_SKIP_DQ call and the matching
    * RFA_BWD_SKIP_DKDV call).  Eligible: dense calls (cu_seqlens NULL, no half selection) with D == 128. */
   void *ds_scratch;
+  int32_t window, window_left, window_right; /* as in rfa_fwd_args (a bounded window_left is not eligible for ds_scratch) */
 } rfa_bwd_args;
 
 enum {

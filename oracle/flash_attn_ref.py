@@ -48,16 +48,33 @@ __all__ = [
 _CHUNK = 1024  # query rows per score block (bounds memory, not a numerical choice)
 
 
-def _mask(sq0: int, nq: int, lq: int, lk: int, causal: bool, device):
-    """bool (nq, lk): True where key j is visible to query row sq0+i (bottom-right aligned)."""
-    if not causal:
+def _window(causal, window):
+    """(left, right) with -1 = unbounded; causal forces right = 0 (flash_attn >= 2.3 semantics)"""
+    wl, wr = (-1, -1) if window is None else (int(window[0]), int(window[1]))
+    wl = -1 if wl is None or wl < 0 else wl
+    wr = -1 if wr is None or wr < 0 else wr
+    if causal:
+        wr = 0
+    return wl, wr
+
+
+def _mask(sq0: int, nq: int, lq: int, lk: int, causal: bool, device, window=None):
+    """bool (nq, lk): True where key j is visible to query row sq0+i (bottom-right aligned):
+    i + (lk - lq) - left <= j <= i + (lk - lq) + right   (each bound only when it is set)."""
+    wl, wr = _window(causal, window)
+    if wl < 0 and wr < 0:
         return None
-    qi = torch.arange(sq0, sq0 + nq, device=device).unsqueeze(1)
+    qi = torch.arange(sq0, sq0 + nq, device=device).unsqueeze(1) + (lk - lq)
     kj = torch.arange(lk, device=device).unsqueeze(0)
-    return kj <= qi + (lk - lq)
+    m = torch.ones((nq, lk), dtype=torch.bool, device=device)
+    if wr >= 0:
+        m &= kj <= qi + wr
+    if wl >= 0:
+        m &= kj >= qi - wl
+    return m
 
 
-def _fwd_one(q, k, v, scale, causal):
+def _fwd_one(q, k, v, scale, causal, window=None):
     """q (Lq,H,D), k,v (Lk,Hk,D) -> out fp32 (Lq,H,D), lse fp32 (H,Lq)."""
     Lq, H, D = q.shape
     Lk, Hk, _ = k.shape
@@ -72,7 +89,7 @@ def _fwd_one(q, k, v, scale, causal):
     for s0 in range(0, Lq, _CHUNK):
         n = min(_CHUNK, Lq - s0)
         s = torch.matmul(qf[:, s0:s0 + n], kf.transpose(1, 2)) * scale        # (H,n,Lk)
-        m = _mask(s0, n, Lq, Lk, causal, q.device)
+        m = _mask(s0, n, Lq, Lk, causal, q.device, window)
         if m is not None:
             s = s.masked_fill(~m, float("-inf"))
         l = torch.logsumexp(s, dim=-1)                                         # -inf for empty rows
@@ -84,7 +101,7 @@ def _fwd_one(q, k, v, scale, causal):
     return out.permute(1, 0, 2), lse
 
 
-def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None):
+def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None, window=None):
     """returns fp32 dq (Lq,H,D), dk, dv (Lk,Hk,D).  lse (H,Lq); delta (H,Lq) overrides rowsum(dO*O)."""
     Lq, H, D = q.shape
     Lk, Hk, _ = k.shape
@@ -103,7 +120,7 @@ def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None):
             n = min(_CHUNK, Lq - s0)
             s = torch.matmul(qf[:, s0:s0 + n], kf.transpose(1, 2)) * scale
             p = torch.exp(s - lse[:, s0:s0 + n].unsqueeze(-1))
-            m = _mask(s0, n, Lq, Lk, causal, q.device)
+            m = _mask(s0, n, Lq, Lk, causal, q.device, window)
             if m is not None:
                 p = torch.where(m, p, torch.zeros_like(p))
             dp = torch.matmul(dof[:, s0:s0 + n], vf.transpose(1, 2))
@@ -118,7 +135,6 @@ def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None):
 
 def _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes):
     assert not dropout_p, "oracle: dropout is not restated (the reference path uses dropout_p=0)"
-    assert window_size_left in (-1, None) and window_size_right in (-1, 0, None), "oracle: no sliding window"
     assert not softcap, "oracle: softcap not restated"
     assert alibi_slopes is None, "oracle: alibi not restated"
 
@@ -141,7 +157,7 @@ def _flash_attn_forward(
     B = q.shape[0]
     outs, lses = [], []
     for b in range(B):
-        o, l = _fwd_one(q[b], k[b], v[b], softmax_scale, causal)
+        o, l = _fwd_one(q[b], k[b], v[b], softmax_scale, causal, (window_size_left, window_size_right))
         outs.append(o)
         lses.append(l)
     out = torch.stack(outs).to(q.dtype)
@@ -175,7 +191,8 @@ def _flash_attn_backward(
     B = q.shape[0]
     ds = []
     for b in range(B):
-        gq, gk, gv = _bwd_one(dout[b], q[b], k[b], v[b], out[b], softmax_lse[b], softmax_scale, causal)
+        gq, gk, gv = _bwd_one(dout[b], q[b], k[b], v[b], out[b], softmax_lse[b], softmax_scale, causal,
+                              window=(window_size_left, window_size_right))
         dq[b].copy_(gq.to(dq.dtype))
         dk[b].copy_(gk.to(dk.dtype))
         dv[b].copy_(gv.to(dv.dtype))
@@ -213,7 +230,8 @@ def _flash_attn_varlen_forward(
     cq = [int(x) for x in cu_seqlens_q.tolist()]
     ck = [int(x) for x in cu_seqlens_k.tolist()]
     for i in range(len(cq) - 1):
-        o, l = _fwd_one(q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]], softmax_scale, causal)
+        o, l = _fwd_one(q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]], softmax_scale, causal,
+                        (window_size_left, window_size_right))
         out[cq[i]:cq[i + 1]] = o
         lse[:, cq[i]:cq[i + 1]] = l
     return out.to(q.dtype), lse, None, None
@@ -250,7 +268,8 @@ def _flash_attn_varlen_backward(
     for i in range(len(cq) - 1):
         a, b = cq[i], cq[i + 1]
         c, d = ck[i], ck[i + 1]
-        gq, gk, gv = _bwd_one(dout[a:b], q[a:b], k[c:d], v[c:d], out[a:b], softmax_lse[:, a:b], softmax_scale, causal)
+        gq, gk, gv = _bwd_one(dout[a:b], q[a:b], k[c:d], v[c:d], out[a:b], softmax_lse[:, a:b], softmax_scale, causal,
+                              window=(window_size_left, window_size_right))
         dq[a:b] = gq.to(dq.dtype)
         dk[c:d] = gk.to(dk.dtype)
         dv[c:d] = gv.to(dv.dtype)
@@ -262,7 +281,7 @@ def _flash_attn_varlen_backward(
 # (`from flash_attn import flash_attn_qkvpacked_func, ...`, test/test_zigzag_ring_flash_attn_func.py:2).
 # Independent formulation: plain softmax attention in fp64 with torch autograd.
 # --------------------------------------------------------------------------------------------
-def full_attention_fp64(q, k, v, causal, softmax_scale=None):
+def full_attention_fp64(q, k, v, causal, softmax_scale=None, window=None):
     """q (B,Sq,H,D) k/v (B,Sk,Hk,D) any float dtype -> out fp64 (B,Sq,H,D), lse fp64 (B,H,Sq).
     Differentiable (autograd) — the independent reference the oracle itself is pinned to."""
     B, Sq, H, D = q.shape
@@ -272,8 +291,8 @@ def full_attention_fp64(q, k, v, causal, softmax_scale=None):
     kd = k.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
     vd = v.double().permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
     s = torch.matmul(qd, kd.transpose(-1, -2)) * scale
-    if causal:
-        m = _mask(0, Sq, Sq, Sk, True, q.device)
+    m = _mask(0, Sq, Sq, Sk, causal, q.device, window)
+    if m is not None:
         s = s.masked_fill(~m, float("-inf"))
     lse = torch.logsumexp(s, dim=-1)
     p = torch.softmax(s, dim=-1)

@@ -86,6 +86,8 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.B = a->B; p.H = a->H; p.Hk = a->Hk; p.D = a->D; p.Sq = a->Sq; p.Sk = a->Sk;
   p.q_half = a->q_half; p.k_half = a->k_half;
   p.causal = a->causal ? 1 : 0; p.acc_init = a->acc_init ? 1 : 0;
+  p.wl = (a->window && a->window_left >= 0) ? a->window_left : -1;
+  p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
   const int rows = fwd_qrows_per_block();
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
@@ -127,7 +129,8 @@ static bool bwd_needs_ws(const rfa_bwd_args* a) {
 
 static bool bwd_spill_eligible(const rfa_bwd_args* a) {
   return a->cu_seqlens_q == nullptr && a->cu_seqlens_k == nullptr && a->D == kHeadDim &&
-         a->q_half == RFA_HALF_FULL && a->k_half == RFA_HALF_FULL && a->B > 0 && a->Sq > 0 && a->Sk > 0;
+         a->q_half == RFA_HALF_FULL && a->k_half == RFA_HALF_FULL && a->B > 0 && a->Sq > 0 && a->Sk > 0 &&
+         !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
 }
 
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
@@ -177,6 +180,8 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.B = a->B; p.H = a->H; p.Hk = a->Hk; p.D = a->D; p.Sq = a->Sq; p.Sk = a->Sk;
   p.q_half = a->q_half; p.k_half = a->k_half;
   p.causal = a->causal ? 1 : 0; p.acc_init = a->acc_init ? 1 : 0;
+  p.wl = (a->window && a->window_left >= 0) ? a->window_left : -1;
+  p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
   p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();
   p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block() - 1) / bwd_dkdv_keys_per_block();

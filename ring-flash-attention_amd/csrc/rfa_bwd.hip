@@ -56,7 +56,7 @@ constexpr int kDqKV = 64;
 template <int kD> constexpr int dq_smem() { return 4 * kDqKV * kD * 2; }   // K[2] V[2]
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging), else zero padded (register staging)
-template <typename T, int kD, bool kFullD>
+template <typename T, int kD, bool kFullD, bool kWin>
 __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -114,9 +114,18 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   const float dlt = p.delta[qbatch * p.delta_batch + (int64_t)h * p.delta_head + arow];
 
   const int qend = (qwg0 + kDqRows < lq) ? qwg0 + kDqRows : lq;
+  // Attention band: query row i sees keys [i + off - wl, i + off + wr], each bound only if set.  Windowed calls
+  // (a left bound, or a right bound without `causal`) run the kWin instances; the default instances keep the plain
+  // causal logic (hi = causal, wr = 0, no left bound) so that their hot loops stay free of the extra predicates.
+  const bool hi = kWin ? p.wr >= 0 : p.causal != 0;
+  const bool lo = kWin && p.wl >= 0;
+  const int wr = kWin ? p.wr : 0, wl = kWin ? p.wl : 0;
   int kmax = lk;
-  if (p.causal && qend + off < kmax) kmax = qend + off;
+  if (hi && qend + off + wr < kmax) kmax = qend + off + wr;
   const int ntiles = kmax > 0 ? (kmax + kDqKV - 1) / kDqKV : 0;
+  int kmin = lo ? qwg0 + off - wl : 0;
+  kmin = kmin > 0 ? kmin : 0;
+  const int jt0 = (kmin / kDqKV) & ~1;                  // first tile (even: LDS stage = j & 1)
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 
   typedef std::integral_constant<int, 0> stage0_t;
   typedef std::integral_constant<int, 1> stage1_t;
-  load_tile(0, stage0_t{});   // unconditional (rows past the end read as zero): one path into the loop
+  load_tile(jt0, stage0_t{});   // unconditional (rows past the end read as zero): one path into the loop
   write_tile(stage0_t{});
   wait_all_vmem();
   __syncthreads();
@@ -217,10 +226,13 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
     typedef std::integral_constant<int, kStage ^ 1> next_t;
     if (j + 1 < ntiles) load_tile(j + 1, next_t{});
     const int kt0 = j * kDqKV;
-    const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
+    const bool active = (qw0 < lq) && !(hi && kt0 > qw0 + 31 + off + wr) &&
+                        !(lo && kt0 + kDqKV - 1 < qw0 + off - wl);
     if (active) {
-      const bool need_mask = (kt0 + kDqKV > lk) || (p.causal && kt0 + kDqKV - 1 > qw0 + off);
-      const int lim = p.causal ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+      const bool need_mask = (kt0 + kDqKV > lk) || (hi && kt0 + kDqKV - 1 > qw0 + off + wr) ||
+                             (lo && kt0 < qw0 + 31 + off - wl);
+      const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
+      const int lim_lo = lo ? qrow + off - wl : -0x40000000;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x16 s, dp;
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + 32 * t + crow(r, g);
-            s[r] = key > lim ? 0.f : s[r];
+            s[r] = (key > lim || (kWin && key < lim_lo)) ? 0.f : s[r];
           }
         }
 #pragma unroll
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
     if (kDma) wait_all_vmem();                           // the DMA of tile j+1 must have landed before the barrier
     __syncthreads();
   };
-  for (int j = 0; j < ntiles; j += 2) {
+  for (int j = jt0; j < ntiles; j += 2) {
     tile_step(j, stage0_t{});
     if (j + 1 < ntiles) tile_step(j + 1, stage1_t{});
   }
@@ -339,11 +351,11 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging) else zero padded (register staging);
 // kSpill: store dS for rfa_dqs.hip (kD = 128 only)
-template <typename T, int kD, bool kFullD, bool kSpill>
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
-  static_assert(!kSpill || kD == 128, "the dS spill format is defined for head dim 128");
+  static_assert(!kSpill || (kD == 128 && !kWin), "the dS spill path: head dim 128, no window");
   typedef HeadGeo<kD> Geo;
   constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
   constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
@@ -397,13 +409,21 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const float* lsebase0 = p.lse + qbatch * p.lse_batch + (int64_t)h0 * p.lse_head + qs.row0;
   const float* dltbase0 = p.delta + qbatch * p.delta_batch + (int64_t)h0 * p.delta_head + qs.row0;
 
+  // queries that see key j: [j - off - wr, j - off + wl], each bound only if set (kWin: see dq_kernel)
+  const bool hi = kWin ? p.wr >= 0 : p.causal != 0;
+  const bool lo = kWin && p.wl >= 0;
+  const int wr = kWin ? p.wr : 0, wl = kWin ? p.wl : 0;
   int qfirst = 0;
-  if (p.causal) {
-    qfirst = kwg0 - off;
+  if (hi) {
+    qfirst = kwg0 - off - wr;
     if (qfirst < 0) qfirst = 0;
   }
+  int qlast = lq;                              // exclusive
+  if (lo && kwg0 + kKvKeys - off + wl < qlast) qlast = kwg0 + kKvKeys - off + wl;
   const int jt0 = qfirst / kKvQ;
-  const int jt1 = (lq + kKvQ - 1) / kKvQ;     // exclusive
+  int jt1 = (qlast + kKvQ - 1) / kKvQ;         // exclusive
+  if (jt1 <= jt0) jt1 = jt0;                   // nothing visible: no tiles (the unconditional prologue fetch below
+                                               // then reads tile jt0 - 1 >= -1: clamped to 0 there)
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // time, so the (kv head = XCD) L2 serves a tile to all co-resident key blocks.  (Walking upward from
   // jt0, head after head, spreads them over the whole sequence and every tile is re-fetched from HBM per
   // workgroup: 3.5x the fabric traffic, measured.)
-  int ld_g = 0, ld_j = jt1 - 1;                       // (head in group, tile) the next load_tile() fetches
+  int ld_g = 0, ld_j = jt1 > 0 ? jt1 - 1 : 0;         // (head in group, tile) the next load_tile() fetches
   auto load_tile = [&]() {
     const int j = ld_j;
     const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
@@ -573,7 +593,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   for (int f = 0; f < ntile; ++f) {
     if (f + 1 < ntile) load_tile();
     const int qs0 = j * kKvQ + 32 * t;
-    const bool active = (kw0 < lk) && (qs0 < lq) && !(p.causal && qs0 + 31 + off < kw0);
+    const bool active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) &&
+                        !(lo && qs0 + off - wl > kw0 + 31);
     if (active) {
       f32x16 s, dp;
 #pragma unroll
@@ -618,7 +639,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       f32x4 l2v[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
-      const bool need_mask = (qs0 + 32 > lq) || (p.causal && qs0 + off < kw0 + 31);
+      const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) ||
+                             (lo && qs0 + 31 + off - wl > kw0);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -628,7 +650,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = qs0 + crow(r, g);
-          const bool ok = (q < lq) && (!p.causal || krow <= q + off);
+          const bool ok = (q < lq) && (!hi || krow <= q + off + wr) && (!lo || krow >= q + off - wl);
           s[r] = ok ? s[r] : 0.f;
         }
       }
@@ -765,45 +787,51 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   }
 }
 
-template <typename T, int kD, bool kFullD>
+template <typename T, int kD, bool kFullD, bool kWin>
 static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kD, kFullD>, dq_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kD, kFullD, kWin>, dq_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dq_kernel<T, kD, kFullD>), dim3((unsigned)nblocks), dim3(kDqThreads), dq_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((dq_kernel<T, kD, kFullD, kWin>), dim3((unsigned)nblocks), dim3(kDqThreads), dq_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, int kD, bool kFullD, bool kSpill>
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill>, kv_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin>, kv_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B;      // one workgroup per (key block, K/V head)
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T>
+template <typename T, bool kWin>
 static int launch_dq_d(const BwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return launch_dq_t<T, 128, true>(p, stream);
-  if (p.D > 64) return launch_dq_t<T, 128, false>(p, stream);
-  if (p.D == 64) return launch_dq_t<T, 64, true>(p, stream);
-  return launch_dq_t<T, 64, false>(p, stream);
+  if (p.D == 128) return launch_dq_t<T, 128, true, kWin>(p, stream);
+  if (p.D > 64) return launch_dq_t<T, 128, false, kWin>(p, stream);
+  if (p.D == 64) return launch_dq_t<T, 64, true, kWin>(p, stream);
+  return launch_dq_t<T, 64, false, kWin>(p, stream);
 }
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_dq_d<bf16_t>(p, stream) : launch_dq_d<f16_t>(p, stream);
+  if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_dq_d<bf16_t, true>(p, stream) : launch_dq_d<f16_t, true>(p, stream);
+  return dtype == 0 ? launch_dq_d<bf16_t, false>(p, stream) : launch_dq_d<f16_t, false>(p, stream);
 }
-template <typename T>
+template <typename T, bool kWin>
 static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return p.ds != nullptr ? launch_dkdv_t<T, 128, true, true>(p, stream) : launch_dkdv_t<T, 128, true, false>(p, stream);
-  if (p.D > 64) return launch_dkdv_t<T, 128, false, false>(p, stream);
-  if (p.D == 64) return launch_dkdv_t<T, 64, true, false>(p, stream);
-  return launch_dkdv_t<T, 64, false, false>(p, stream);
+  if (p.D == 128) return launch_dkdv_t<T, 128, true, false, kWin>(p, stream);
+  if (p.D > 64) return launch_dkdv_t<T, 128, false, false, kWin>(p, stream);
+  if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin>(p, stream);
+  return launch_dkdv_t<T, 64, false, false, kWin>(p, stream);
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_dkdv_d<bf16_t>(p, stream) : launch_dkdv_d<f16_t>(p, stream);
+  const bool win = windowed(p.causal, p.wl, p.wr);
+  if (p.ds != nullptr && p.D == 128 && !win)      // dS spill instance (rfa_api.cpp only passes ds for eligible calls)
+    return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false>(p, stream)
+                      : launch_dkdv_t<f16_t, 128, true, true, false>(p, stream);
+  if (win) return dtype == 0 ? launch_dkdv_d<bf16_t, true>(p, stream) : launch_dkdv_d<f16_t, true>(p, stream);
+  return dtype == 0 ? launch_dkdv_d<bf16_t, false>(p, stream) : launch_dkdv_d<f16_t, false>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
 int bwd_dkdv_keys_per_block() { return kKvKeys; }

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? nKb * kDsBlockBytes : 0);
 
   const int qend = (qwg0 + kDsRows < lq) ? qwg0 + kDsRows : lq;
-  int kmax = lk;
+  int kmax = lk;                                        // (windowed calls are not eligible for the spill path)
   if (p.causal && qend + off < kmax) kmax = qend + off;
   const int ntiles = kmax > 0 ? (kmax + kDsKV - 1) / kDsKV : 0;
 

@@ -45,7 +45,7 @@ template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * kD
 
 // kD: compiled head dim (128 or 64: half the MFMAs, half the LDS bytes per tile); kFullD: D == kD (LDS-DMA
 // staging, no conditional loads), otherwise D < kD is zero padded through the register staging path
-template <typename T, int kD, bool kFullD>
+template <typename T, int kD, bool kFullD, bool kWin>
 __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -104,9 +104,18 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
   // ---- KV range of this workgroup
   const int qend = (qwg0 + kFwdQRows < lq) ? qwg0 + kFwdQRows : lq;
+  // Attention band: query row i sees keys [i + off - wl, i + off + wr], each bound only if set.  Windowed calls
+  // (a left bound, or a right bound without `causal`) run the kWin instances; the default instances keep the plain
+  // causal logic (hi = causal, wr = 0, no left bound) so that their hot loops stay free of the extra predicates.
+  const bool hi = kWin ? p.wr >= 0 : p.causal != 0;
+  const bool lo = kWin && p.wl >= 0;
+  const int wr = kWin ? p.wr : 0, wl = kWin ? p.wl : 0;
   int kmax = lk;
-  if (p.causal && qend + off < kmax) kmax = qend + off;
+  if (hi && qend + off + wr < kmax) kmax = qend + off + wr;
   const int ntiles = kmax > 0 ? (kmax + kFwdKV - 1) / kFwdKV : 0;
+  int kmin = lo ? qwg0 + off - wl : 0;
+  kmin = kmin > 0 ? kmin : 0;
+  const int jt0 = (kmin / kFwdKV) / kFwdStages * kFwdStages;   // first tile (aligned to the LDS ring: stage = j % stages)
 
   // ---- K/V tile staging.  Raw buffer loads: the per-thread byte offsets are fixed for the whole kernel,
   // the tile advance lives in the scalar descriptor, rows past the end of the sequence read as zero.
@@ -209,11 +218,11 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   // in front of the first MFMA of every tile.
   // The DMA path keeps kFwdStages - 1 tiles in flight; the register path (D < 128) only one.
   constexpr int kDist = kDma ? kFwdStages - 1 : 1;
-  load_tile(0, std::integral_constant<int, 0>{});
+  load_tile(jt0, std::integral_constant<int, 0>{});
   write_tile(std::integral_constant<int, 0>{});
   wait_all_vmem();          // Q fragment loads too: nothing the compiler tracks may stay pending into the loop
   __syncthreads();
-  if (kDist == 2) load_tile(1, std::integral_constant<int, 1>{});   // (rows past the end: descriptor range 0)
+  if (kDist == 2) load_tile(jt0 + 1, std::integral_constant<int, 1>{});   // (rows past the end: descriptor range 0)
 
   // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by the ring depth),
   // so every LDS address in here is a per-lane table entry plus an instruction immediate.
@@ -227,7 +236,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     if (more) load_tile(j + kDist, fill_t{});
 
     const int kt0 = j * kFwdKV;
-    const bool active = (qw0 < lq) && !(p.causal && kt0 > qw0 + 31 + off);
+    const bool active = (qw0 < lq) && !(hi && kt0 > qw0 + 31 + off + wr) &&
+                        !(lo && kt0 + kFwdKV - 1 < qw0 + off - wl);
     if (active) {
       // ---------------- S^T = K Q^T ----------------
       f32x16 s[2];
@@ -258,15 +268,17 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
       }
       // ---------------- mask ----------------
-      const bool need_mask = (kt0 + kFwdKV > lk) || (p.causal && kt0 + kFwdKV - 1 > qw0 + off);
+      const bool need_mask = (kt0 + kFwdKV > lk) || (hi && kt0 + kFwdKV - 1 > qw0 + off + wr) ||
+                             (lo && kt0 < qw0 + 31 + off - wl);
       if (need_mask) {
-        const int lim = p.causal ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+        const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
+        const int lim_lo = lo ? qrow + off - wl : -0x40000000;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + 32 * t + crow(r, g);
-            if (key > lim) s[t][r] = -INFINITY;
+            if (key > lim || (kWin && key < lim_lo)) s[t][r] = -INFINITY;
           }
       }
       // ---------------- online softmax ----------------
@@ -331,13 +343,13 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
     __syncthreads();
   };
   if (kFwdStages == 3) {
-    for (int j = 0; j < ntiles; j += 3) {
+    for (int j = jt0; j < ntiles; j += 3) {
       tile_step(j, std::integral_constant<int, 0>{});
       if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
       if (j + 2 < ntiles) tile_step(j + 2, std::integral_constant<int, 2 % kFwdStages>{});
     }
   } else {
-    for (int j = 0; j < ntiles; j += 2) {
+    for (int j = jt0; j < ntiles; j += 2) {
       tile_step(j, std::integral_constant<int, 0>{});
       if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
     }
@@ -400,26 +412,27 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   }
 }
 
-template <typename T, int kD, bool kFullD>
+template <typename T, int kD, bool kFullD, bool kWin>
 static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD>, fwd_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin>, fwd_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T>
+template <typename T, bool kWin>
 static int launch_fwd_d(const FwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return launch_fwd_t<T, 128, true>(p, stream);
-  if (p.D > 64) return launch_fwd_t<T, 128, false>(p, stream);
-  if (p.D == 64) return launch_fwd_t<T, 64, true>(p, stream);
-  return launch_fwd_t<T, 64, false>(p, stream);
+  if (p.D == 128) return launch_fwd_t<T, 128, true, kWin>(p, stream);
+  if (p.D > 64) return launch_fwd_t<T, 128, false, kWin>(p, stream);
+  if (p.D == 64) return launch_fwd_t<T, 64, true, kWin>(p, stream);
+  return launch_fwd_t<T, 64, false, kWin>(p, stream);
 }
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
-  return dtype == 0 ? launch_fwd_d<bf16_t>(p, stream) : launch_fwd_d<f16_t>(p, stream);
+  if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_fwd_d<bf16_t, true>(p, stream) : launch_fwd_d<f16_t, true>(p, stream);
+  return dtype == 0 ? launch_fwd_d<bf16_t, false>(p, stream) : launch_fwd_d<f16_t, false>(p, stream);
 }
 
 int fwd_qrows_per_block() { return kFwdQRows; }

@@ -8,6 +8,9 @@
 
 namespace rfa {
 
+// windowed instances are needed for a left bound, or for a right bound that is not the plain causal one
+inline bool windowed(int causal, int wl, int wr) { return wl >= 0 || (wr >= 0 && !causal); }
+
 // launcher status codes (rfa_api.cpp maps them to rfa_status)
 enum { kLaunchOk = 0, kLaunchFailed = -1, kLaunchAttrFailed = -2 };
 
@@ -40,6 +43,8 @@ struct FwdParams {
   int B, H, Hk, D, Sq, Sk;
   int q_half, k_half;
   int causal, acc_init;
+  int wl, wr;          // visible keys of query i: i + (Sk - Sq) - wl <= j <= i + (Sk - Sq) + wr; -1 = unbounded
+                       // (causal is folded in by the API layer: wr = 0)
   int nqblk;
   float scale;
 };
@@ -65,6 +70,7 @@ struct BwdParams {
   int B, H, Hk, D, Sq, Sk;
   int q_half, k_half;
   int causal, acc_init;
+  int wl, wr;          // attention window as in FwdParams (causal: wr = 0)
   int kv_f32;          // dk / dv point to fp32 buffers (overwritten), strides in fp32 elements
   void* ds;            // dS spill scratch (rfa_dqs.hip) or nullptr: dkdv_kernel stores its packed dS blocks there
   int nqblk, nkblk;

@@ -38,6 +38,7 @@ class FwdArgs(C.Structure):
         ("softmax_scale", C.c_float),
         ("causal", C.c_int32),
         ("dtype", C.c_int32),
+        ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
     ]
 
 
@@ -76,6 +77,7 @@ class BwdArgs(C.Structure):
         ("dtype", C.c_int32),
         ("phases", C.c_int32),
         ("ds_scratch", C.c_void_p),
+        ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
     ]
 
 

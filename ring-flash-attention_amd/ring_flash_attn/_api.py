@@ -54,12 +54,28 @@ def _compilable(fn, lower):
     return public
 
 
-def _check_unsupported(dropout_p, window_size, alibi_slopes):
+def _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=False):
+    """dropout is not implemented (nor usable in the reference's ring schedules, README.md:158-159).  Sliding windows
+    are implemented in the kernels (flash_attn semantics) and usable wherever ONE kernel call sees all the keys a
+    query may attend to: every function on a single-rank group, and llama3_flash_attn_varlen_func on any group (it
+    gathers K/V) — the same coverage the reference gets from forwarding window_size to flash_attn.  The ring / zigzag
+    / stripe schedules over several ranks would apply the window per block, which is wrong: they raise."""
     assert alibi_slopes is None
     if dropout_p and dropout_p > 0:
         raise NotImplementedError("ring_flash_attn: dropout is not supported (as in the reference)")
-    if tuple(window_size) != (-1, -1):
-        raise NotImplementedError("ring_flash_attn: sliding window is not supported (as in the reference)")
+    if not windows_ok and has_window(window_size):
+        raise NotImplementedError("ring_flash_attn: sliding window over a multi-rank ring is not supported (as in the "
+                                  "reference); use llama3_flash_attn_varlen_func or a single-rank group")
+
+
+def has_window(window_size) -> bool:
+    return window_size is not None and (window_size[0] >= 0 or window_size[1] >= 0)
+
+
+def window_ok_for(group) -> bool:
+    from .utils import group_rank_world
+
+    return group_rank_world(group)[1] == 1
 
 
 def make_autograd_function(name, forward_impl, backward_impl, n_lead):
@@ -74,7 +90,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
              return_softmax, group) = rest[n_lead:]
             if softmax_scale is None:
                 softmax_scale = q.shape[-1] ** (-0.5)
-            _check_unsupported(dropout_p, window_size, alibi_slopes)
+            _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=window_ok_for(group))
             q, k, v = _prep_qkv(q, k, v, group)
             tensors_lead = ()
             if n_lead:
@@ -91,6 +107,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
             ctx.causal = causal
             ctx.deterministic = deterministic
             ctx.group = group
+            ctx.window_size = tuple(window_size)
             return out if not return_softmax else (out, softmax_lse, None)
 
         @staticmethod
@@ -99,7 +116,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
             dq, dk, dv = backward_impl(
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
                 softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
-                window_size=(-1, -1), alibi_slopes=None, deterministic=ctx.deterministic,
+                window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic,
             )
             return (dq, dk, dv) + (None,) * (n_lead + 8)
 
@@ -127,7 +144,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
              return_softmax, group) = rest[n_lead:]
             if softmax_scale is None:
                 softmax_scale = q.shape[-1] ** (-0.5)
-            _check_unsupported(dropout_p, window_size, alibi_slopes)
+            _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=window_ok_for(group))
             q, k, v = _prep_qkv(q, k, v, group)
             tensors_lead = ()
             if n_lead:
@@ -144,6 +161,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
             ctx.causal = causal
             ctx.deterministic = deterministic
             ctx.group = group
+            ctx.window_size = tuple(window_size)
             ctx.packed_meta = (packed.shape, packed.dtype, packed.device)
             return out if not return_softmax else (out, softmax_lse, None)
 
@@ -160,7 +178,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
             dq, dk, dv = backward_impl(
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
                 softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
-                window_size=(-1, -1), alibi_slopes=None, deterministic=ctx.deterministic,
+                window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic,
                 out_grads=out_grads,
             )
             got = (dq, dk, dv)[3 - n_packed:]
@@ -216,9 +234,9 @@ def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None):
               deterministic=False, return_attn_probs=False, group=None):
         from ._ops import single_device_attention
 
-        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=True)
         assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
-        return single_device_attention(q, k, v, None, 0, softmax_scale, causal, return_attn_probs)
+        return single_device_attention(q, k, v, None, 0, softmax_scale, causal, return_attn_probs, window_size)
 
     def lower_kv(q, kv, *a, **kw):
         return lower(q, kv[:, :, 0], kv[:, :, 1], *a, **kw)
@@ -258,9 +276,10 @@ def make_varlen_api(fn, prefix):
               window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
         from ._ops import single_device_attention
 
-        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=True)
         assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
-        return single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs)
+        return single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs,
+                                       window_size)
 
     def lower_kv(q, kv, *a, **kw):
         return lower(q, kv[:, 0], kv[:, 1], *a, **kw)

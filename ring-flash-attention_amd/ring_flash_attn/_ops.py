@@ -4,8 +4,9 @@ The reference runs every test a second time under `torch.compile` (test/test.sh:
 test/test_zigzag_ring_flash_attn_func.py:105-108).  The C-ABI calls of this package are ctypes
 calls dynamo cannot trace, so they are registered as custom operators with fake (meta) kernels:
 
-    rfa::attn_fwd(q, k, v, cu_seqlens?, max_seqlen, softmax_scale, causal) -> (out, lse)
-    rfa::attn_bwd(dout, q, k, v, out, lse, cu_seqlens?, max_seqlen, softmax_scale, causal, deterministic)
+    rfa::attn_fwd(q, k, v, cu_seqlens?, max_seqlen, softmax_scale, causal, window_left, window_right) -> (out, lse)
+    rfa::attn_bwd(dout, q, k, v, out, lse, cu_seqlens?, max_seqlen, softmax_scale, causal, window_left,
+                  window_right, deterministic)
                                                                         -> (dq, dk, dv)
 
 with an autograd formula linking them.  When a public function is traced by dynamo and the process
@@ -37,17 +38,17 @@ def _vl(cu_seqlens, max_seqlen):
 
 @torch.library.custom_op("rfa::attn_fwd", mutates_args=())
 def attn_fwd(q: Tensor, k: Tensor, v: Tensor, cu_seqlens: Optional[Tensor], max_seqlen: int,
-             softmax_scale: float, causal: bool) -> Tuple[Tensor, Tensor]:
+             softmax_scale: float, causal: bool, window_left: int, window_right: int) -> Tuple[Tensor, Tensor]:
     varlen = cu_seqlens is not None
     out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     lse = torch.empty(_lse_shape(q, varlen), dtype=torch.float32, device=q.device)
     get_backend().fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse,
-                      **_vl(cu_seqlens, max_seqlen))
+                      window=(window_left, window_right), **_vl(cu_seqlens, max_seqlen))
     return out, lse
 
 
 @attn_fwd.register_fake
-def _attn_fwd_fake(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal):
+def _attn_fwd_fake(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, window_left, window_right):
     return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
             torch.empty(_lse_shape(q, cu_seqlens is not None), dtype=torch.float32, device=q.device))
 
@@ -55,7 +56,7 @@ def _attn_fwd_fake(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal):
 @torch.library.custom_op("rfa::attn_bwd", mutates_args=())
 def attn_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor,
              cu_seqlens: Optional[Tensor], max_seqlen: int, softmax_scale: float, causal: bool,
-             deterministic: bool) -> Tuple[Tensor, Tensor, Tensor]:
+             window_left: int, window_right: int, deterministic: bool) -> Tuple[Tensor, Tensor, Tensor]:
     be = get_backend()
     varlen = cu_seqlens is not None
     if dout.stride(-1) != 1:
@@ -71,19 +72,21 @@ def attn_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Te
     dk = torch.empty(k.shape, dtype=k.dtype, device=k.device)
     dv = torch.empty(v.shape, dtype=v.dtype, device=v.device)
     be.bwd(dout, q, k, v, lse, delta, softmax_scale=softmax_scale, causal=causal, dq=dq, dk=dk, dv=dv,
-           deterministic=deterministic, **_vl(cu_seqlens, max_seqlen))
+           deterministic=deterministic, window=(window_left, window_right), **_vl(cu_seqlens, max_seqlen))
     return dq, dk, dv
 
 
 @attn_bwd.register_fake
-def _attn_bwd_fake(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale, causal, deterministic):
+def _attn_bwd_fake(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale, causal, window_left, window_right,
+                   deterministic):
     return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
             torch.empty(k.shape, dtype=k.dtype, device=k.device),
             torch.empty(v.shape, dtype=v.dtype, device=v.device))
 
 
 def _setup_context(ctx, inputs, output):
-    q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal = inputs
+    q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, window_left, window_right = inputs
+    ctx.window = (window_left, window_right)
     out, lse = output
     ctx.save_for_backward(q, k, v, out, lse, cu_seqlens)
     ctx.max_seqlen = max_seqlen
@@ -94,16 +97,18 @@ def _setup_context(ctx, inputs, output):
 def _backward(ctx, dout, dlse):
     q, k, v, out, lse, cu_seqlens = ctx.saved_tensors
     dq, dk, dv = torch.ops.rfa.attn_bwd(dout, q, k, v, out, lse, cu_seqlens, ctx.max_seqlen, ctx.softmax_scale,
-                                        ctx.causal, False)
-    return dq, dk, dv, None, None, None, None
+                                        ctx.causal, ctx.window[0], ctx.window[1], False)
+    return dq, dk, dv, None, None, None, None, None, None
 
 
 torch.library.register_autograd("rfa::attn_fwd", _backward, setup_context=_setup_context)
 
 
-def single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs):
+def single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs,
+                            window_size=(-1, -1)):
     """what every schedule of this package reduces to on a single-rank group, as traceable operators"""
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
-    out, lse = torch.ops.rfa.attn_fwd(q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal))
+    out, lse = torch.ops.rfa.attn_fwd(q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal),
+                                      int(window_size[0]), int(window_size[1]))
     return (out, lse, None) if return_attn_probs else out

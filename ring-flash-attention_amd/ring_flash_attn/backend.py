@@ -79,7 +79,7 @@ class HipBackend:
     # ------------------------------------------------------------------ forward
     def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
             max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL, k_half=HALF_FULL,
-            out=None, lse=None, out_acc=None, lse_acc=None, acc_init=False):
+            out=None, lse=None, out_acc=None, lse_acc=None, acc_init=False, window=(-1, -1)):
         """Block attention.  Plain mode fills (out, lse); accumulate mode merges into the fp32
         (out_acc, lse_acc) pair (fused update_out_and_lse).  Dense: q (B,Sq,H,D); varlen: (T,H,D)."""
         self._check_dev(q, k, v, out, lse, out_acc, lse_acc)
@@ -108,6 +108,8 @@ class HipBackend:
         a.q_half, a.k_half = q_half, k_half
         a.softmax_scale = float(softmax_scale)
         a.causal = 1 if causal else 0
+        if window is not None and (window[0] >= 0 or window[1] >= 0):
+            a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         _C.check(self.lib.rfa_fwd(C.byref(a), _stream(q)), "rfa_fwd")
 
@@ -134,7 +136,8 @@ class HipBackend:
     def bwd(self, dout, q, k, v, lse, delta, *, softmax_scale, causal, cu_seqlens_q=None,
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL,
             k_half=HALF_FULL, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None,
-            acc_init=False, deterministic=False, phases=_C.BWD_ALL, partials=None, ds_scratch=None):
+            acc_init=False, deterministic=False, phases=_C.BWD_ALL, partials=None, ds_scratch=None,
+            window=(-1, -1)):
         """dQ/dK/dV of one block.  Plain outputs (io dtype) or `+=` into fp32 accumulators.
         phases=BWD_COMPUTE / BWD_REDUCE splits the call so a ring step can overlap the kernels
         with the arrival of the dk/dv accumulators it adds into: the COMPUTE call RETURNS the buffer
@@ -178,6 +181,8 @@ class HipBackend:
         a.softmax_scale = float(softmax_scale)
         a.causal = 1 if causal else 0
         a.deterministic = 1 if deterministic else 0
+        if window is not None and (window[0] >= 0 or window[1] >= 0):
+            a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         a.phases = phases
         # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of

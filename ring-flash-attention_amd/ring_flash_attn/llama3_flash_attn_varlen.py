@@ -130,7 +130,7 @@ def llama3_flash_attn_varlen_forward(
 
     if world_size == 1:
         be.fwd(q, k[local_k_slice], v[local_k_slice], softmax_scale=softmax_scale, causal=causal,
-               out=out, lse=lse, **vl)
+               out=out, lse=lse, window=window_size, **vl)
         return out, lse
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
@@ -154,7 +154,7 @@ def llama3_flash_attn_varlen_forward(
             pending = post_gather(gi + 1)          # next super-group's K/V arrive beside this one's attention
         q_slice = slice(g0 * nheads // nheads_k, (g0 + hs) * nheads // nheads_k)
         be.fwd(q[:, q_slice], buf[0][local_k_slice], buf[1][local_k_slice],
-               softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], **vl)
+               softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], window=window_size, **vl)
 
     return out, lse
 
@@ -204,7 +204,7 @@ def llama3_flash_attn_varlen_backward(
             dk.zero_()
             dv.zero_()
         be.bwd(dout, q, k[local_k_slice], v[local_k_slice], softmax_lse, delta, softmax_scale=softmax_scale,
-               causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, **vl)
+               causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, window=window_size, **vl)
         return dq, dk, dv
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
@@ -252,7 +252,7 @@ def llama3_flash_attn_varlen_backward(
         be.bwd(dout[:, q_slice], q[:, q_slice], kv[0][local_k_slice], kv[1][local_k_slice],
                softmax_lse[q_slice], delta[q_slice], softmax_scale=softmax_scale, causal=causal,
                dq=dq[:, q_slice], dk=dkv[0][local_k_slice], dv=dkv[1][local_k_slice],
-               deterministic=deterministic, **vl)
+               deterministic=deterministic, window=window_size, **vl)
         if job is not None:
             finish(job)                          # group gi-1's exchange ran beside the kernels just enqueued
         dst = (dk, dv) if whole else (rs_out[gi % 2][0], rs_out[gi % 2][1])
@@ -272,7 +272,7 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
                 return_softmax, group):
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
-        _check_unsupported(dropout_p, window_size, alibi_slopes)
+        _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=True)   # K/V are gathered: one kernel sees them all
         if q.stride(-1) != 1:
             q = q.contiguous()
         k = k.contiguous()      # all-gather source
@@ -290,6 +290,7 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
         ctx.causal = causal
         ctx.deterministic = deterministic
         ctx.group = group
+        ctx.window_size = tuple(window_size)
         return out if not return_softmax else (out, softmax_lse, None)
 
     @staticmethod
@@ -297,7 +298,7 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
         q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k = ctx.saved_tensors
         dq, dk, dv = llama3_flash_attn_varlen_backward(
             ctx.group, dout, q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, *ctx.static,
-            softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal, window_size=(-1, -1),
+            softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal, window_size=ctx.window_size,
             alibi_slopes=None, deterministic=ctx.deterministic,
         )
         return (dq, dk, dv) + (None,) * 15

@@ -34,7 +34,7 @@ def ring_flash_attn_forward(
     if comm.world_size == 1:
         out = torch.empty_like(q)
         lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
-        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse, window=window_size)
         return out, lse
 
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
@@ -90,7 +90,7 @@ def ring_flash_attn_backward(
     if kv_comm.world_size == 1:
         dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=causal,
-               dq=dq, dk=dk, dv=dv, deterministic=deterministic)
+               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size)
         return dq, dk, dv
 
     dq = None

@@ -80,7 +80,7 @@ def zigzag_ring_flash_attn_varlen_forward(
     if comm.world_size == 1:
         out = torch.empty_like(q)
         lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
-        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, **vl)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size, **vl)
         return out, lse
 
     out_acc = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
@@ -141,7 +141,7 @@ def zigzag_ring_flash_attn_varlen_backward(
     if kv_comm.world_size == 1:
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-               dq=dq, dk=dk, dv=dv, deterministic=deterministic, **vl)
+               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, **vl)
         return dq, dk, dv
 
     dq = torch.empty((T, H, D), dtype=torch.float32, device=q.device)

@@ -11,8 +11,8 @@ tests and benchmarks run on an MI355X by putting `ring-flash-attention_amd/shims
 (INTEGRATION.md route B; the directory is opt-in so that importing `ring_flash_attn` never shadows a real
 flash_attn install).  There is no CPU path: CPU tensors raise.
 
-Unsupported features raise instead of being silently ignored: dropout_p != 0, sliding windows,
-softcap, alibi_slopes, paged KV (block_table / leftpad_k / seqused_k), return_softmax / S_dmask.
+Sliding windows (window_size_left / window_size_right) are supported by the kernels.  Unsupported features
+raise instead of being silently ignored: dropout_p != 0, softcap, alibi_slopes, paged KV (block_table / leftpad_k / seqused_k), return_softmax / S_dmask.
 """
 import math
 from typing import Optional, Tuple
@@ -54,8 +54,6 @@ __all__ = [
 def _reject(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes, causal, **paged):
     if dropout_p:
         raise NotImplementedError("flash_attn (rfa): dropout_p != 0 is not supported")
-    if window_size_left not in (-1, None) or not (window_size_right in (-1, None) or (causal and window_size_right == 0)):
-        raise NotImplementedError("flash_attn (rfa): sliding-window attention is not supported")
     if softcap:
         raise NotImplementedError("flash_attn (rfa): softcap is not supported")
     if alibi_slopes is not None:
@@ -63,6 +61,12 @@ def _reject(dropout_p, window_size_left, window_size_right, softcap, alibi_slope
     for name, val in paged.items():
         if val is not None:
             raise NotImplementedError(f"flash_attn (rfa): {name} (paged / left-padded KV) is not supported")
+
+
+def _win(window_size_left, window_size_right):
+    wl = -1 if window_size_left is None else int(window_size_left)
+    wr = -1 if window_size_right is None else int(window_size_right)
+    return (wl, wr)
 
 
 def _unit_last(t: torch.Tensor) -> torch.Tensor:
@@ -79,7 +83,8 @@ def _flash_attn_forward(q, k, v, dropout_p, softmax_scale, causal, window_size_l
     B, Sq, H, _ = q.shape
     out = torch.empty_like(q, memory_format=torch.contiguous_format)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
-    get_backend().fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse)
+    get_backend().fwd(q, k, v, softmax_scale=softmax_scale, causal=causal, out=out, lse=lse,
+                      window=_win(window_size_left, window_size_right))
     return out, lse, None, None
 
 
@@ -95,7 +100,7 @@ def _flash_attn_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, dropout_p,
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     be.bwd_preprocess(dout, out, delta)
     be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=causal,
-           dq=dq, dk=dk, dv=dv, deterministic=deterministic)
+           dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=_win(window_size_left, window_size_right))
     return delta
 
 
@@ -113,7 +118,8 @@ def _flash_attn_varlen_forward(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q
     lse = alloc((H, T), dtype=torch.float32, device=q.device)
     get_backend().fwd(q, k, v, softmax_scale=softmax_scale, causal=causal,
                       cu_seqlens_q=cu_seqlens_q.int(), cu_seqlens_k=cu_seqlens_k.int(),
-                      max_seqlen_q=max_seqlen_q, max_seqlen_k=max_seqlen_k, out=out, lse=lse)
+                      max_seqlen_q=max_seqlen_q, max_seqlen_k=max_seqlen_k, out=out, lse=lse,
+                      window=_win(window_size_left, window_size_right))
     return out, lse, None, None
 
 
@@ -133,22 +139,24 @@ def _flash_attn_varlen_backward(dout, q, k, v, out, softmax_lse, dq, dk, dv, cu_
         dq.zero_(), dk.zero_(), dv.zero_()
     be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=causal,
            cu_seqlens_q=cq, cu_seqlens_k=ck, max_seqlen_q=max_seqlen_q, max_seqlen_k=max_seqlen_k,
-           dq=dq, dk=dk, dv=dv, deterministic=deterministic)
+           dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=_win(window_size_left, window_size_right))
     return delta
 
 
 # ------------------------------------------------------------------------------ public single-device API
 class _FlashAttnFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale, causal, deterministic, return_lse, cu_q, cu_k, max_q, max_k):
+    def forward(ctx, q, k, v, softmax_scale, causal, deterministic, return_lse, cu_q, cu_k, max_q, max_k, wl, wr):
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         if cu_q is None:
-            out, lse, _, _ = _flash_attn_forward(q, k, v, 0.0, softmax_scale, causal)
+            out, lse, _, _ = _flash_attn_forward(q, k, v, 0.0, softmax_scale, causal, wl, wr)
         else:
-            out, lse, _, _ = _flash_attn_varlen_forward(q, k, v, cu_q, cu_k, max_q, max_k, 0.0, softmax_scale, causal)
+            out, lse, _, _ = _flash_attn_varlen_forward(q, k, v, cu_q, cu_k, max_q, max_k, 0.0, softmax_scale, causal,
+                                                        wl, wr)
         ctx.save_for_backward(q, k, v, out, lse, cu_q, cu_k)
         ctx.args = (softmax_scale, causal, deterministic, max_q, max_k)
+        ctx.window = (wl, wr)
         ctx.mark_non_differentiable(lse)
         return out, lse
 
@@ -158,12 +166,12 @@ class _FlashAttnFunc(torch.autograd.Function):
         softmax_scale, causal, deterministic, max_q, max_k = ctx.args
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         if cu_q is None:
-            _flash_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, 0.0, softmax_scale, causal,
+            _flash_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, 0.0, softmax_scale, causal, *ctx.window,
                                  deterministic=deterministic)
         else:
             _flash_attn_varlen_backward(dout, q, k, v, out, lse, dq, dk, dv, cu_q, cu_k, max_q, max_k, 0.0,
-                                        softmax_scale, causal, deterministic=deterministic)
-        return (dq, dk, dv) + (None,) * 8
+                                        softmax_scale, causal, *ctx.window, deterministic=deterministic)
+        return (dq, dk, dv) + (None,) * 10
 
 
 def _public(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
@@ -171,7 +179,7 @@ def _public(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, ali
     wl, wr = (window_size if window_size is not None else (-1, -1))
     _reject(dropout_p, wl, wr, softcap, alibi_slopes, causal, **paged)
     out, lse = _FlashAttnFunc.apply(q, k, v, softmax_scale, causal, deterministic, return_attn_probs,
-                                    cu_q, cu_k, max_q, max_k)
+                                    cu_q, cu_k, max_q, max_k, *_win(wl, wr))
     return (out, lse, None) if return_attn_probs else out
 
 

@@ -38,23 +38,29 @@ def test_use_ring_attn_switch_and_param_guard(single_rank_group):
     A.use_ring_attn(True)
 
 
-def test_sliding_window_is_not_silently_dropped(single_rank_group):
+def test_sliding_window_is_honoured(single_rank_group):
     """a model configured with a sliding window shorter than the key length must not silently get
-    full causal attention — the window is forwarded like the reference does (hf_adapter.py:121-128) and the
-    operator rejects it loudly; a window that covers the whole key range is a no-op and passes."""
+    full causal attention.  The window is forwarded like the reference does (hf_adapter.py:121-128:
+    window_size=(w, w) when the key length exceeds it) and the kernels implement it (flash_attn semantics);
+    a window that covers the whole key range is a no-op."""
     from ring_flash_attn import backend
     from ring_flash_attn.adapters import hf_adapter as A
+    from oracle import flash_attn_ref as O
     from oracle.oracle_backend import OracleBackend
 
     backend.set_backend(OracleBackend())
     try:
         A.substitute_hf_flash_attn(None, 1)
-        A.update_ring_flash_attn_params(torch.tensor([0, 8], dtype=torch.int32), None)
-        q = torch.randn(1, 8, 2, 16).to(torch.bfloat16)
-        with pytest.raises(NotImplementedError, match="sliding window"):
-            A._ring_attention(q, q, q, dropout=0.0, softmax_scale=None, causal=True, sliding_window=4)
-        out = A._ring_attention(q, q, q, dropout=0.0, softmax_scale=None, causal=True, sliding_window=4096)
-        assert out.shape == q.shape
+        A.update_ring_flash_attn_params(torch.tensor([0, 24], dtype=torch.int32), None)
+        g = torch.Generator().manual_seed(2)
+        q, k, v = (torch.randn(1, 24, 2, 16, generator=g).to(torch.bfloat16) for _ in range(3))
+        full = A._ring_attention(q, k, v, dropout=0.0, softmax_scale=None, causal=True, sliding_window=4096)
+        win = A._ring_attention(q, k, v, dropout=0.0, softmax_scale=None, causal=True, sliding_window=4)
+        ref_full, _ = O.full_attention_fp64(q, k, v, True)
+        ref_win, _ = O.full_attention_fp64(q, k, v, True, window=(4, 4))
+        assert (full.double() - ref_full).abs().max() < 2e-2
+        assert (win.double() - ref_win).abs().max() < 2e-2
+        assert (ref_win - ref_full).abs().max() > 0.1
     finally:
         backend.set_backend(None)
         A.DATA_PARAMS.clear()

@@ -123,8 +123,13 @@ def test_public_functions_autograd(built):
     assert torch.equal(o3, out.detach()[0]) and l3.shape == (H, S)
     with pytest.raises(NotImplementedError):
         FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p=0.1)
-    with pytest.raises(NotImplementedError):
-        FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], window_size=(128, 0), causal=True)
+    # sliding window through the public function: against the oracle with the same window
+    xw = qkv.to(dev).requires_grad_(True)
+    ow = FA.flash_attn_qkvpacked_func(xw, window_size=(128, 0), causal=True)
+    ow.backward(do.to(dev))
+    rw, rlw, _, _ = O._flash_attn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.0, D ** -0.5, True, 128, 0)
+    _check("window out", ow, rw, 2e-2)
+    assert (ow.detach() - out.detach()).abs().max() > 1e-2           # the window changed the result
 
 
 @pytest.mark.parametrize("D", [128, 96])

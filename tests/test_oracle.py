@@ -130,3 +130,38 @@ def test_c_oracle_merge_is_reference_formula(built):
     lib.rfa_ref_merge(P(o2), P(l2), P(bo), P(bl.contiguous()), B, S, H, D)
     assert (o2 - ref_o).abs().max() < 1e-6 and (l2 - ref_l).abs().max() < 1e-6
     assert (l2 - torch.logaddexp(lse, bl)).abs().max() < 1e-6      # == logaddexp
+
+
+@pytest.mark.parametrize("Sq,Sk,causal,window", [
+    (70, 70, True, (16, 0)), (70, 70, False, (9, 5)), (40, 100, True, (30, -1)), (100, 40, False, (-1, 7)),
+    (64, 64, False, (0, 0)),
+])
+def test_oracle_sliding_window_vs_explicit_mask(Sq, Sk, causal, window):
+    """window semantics (flash_attn: key j visible to query i iff i + (Sk-Sq) - left <= j <= i + (Sk-Sq) + right,
+    causal forces right = 0), pinned against an explicitly built boolean mask in fp64 with autograd"""
+    H, Hk, D = 4, 2, 32
+    q, k, v, do = _rand((1, Sq, H, D), 1), _rand((1, Sk, Hk, D), 2), _rand((1, Sk, Hk, D), 3), _rand((1, Sq, H, D), 4)
+    scale = D ** -0.5
+    wl, wr = window
+    if causal:
+        wr = 0
+    qi = torch.arange(Sq).unsqueeze(1) + (Sk - Sq)
+    kj = torch.arange(Sk).unsqueeze(0)
+    vis = torch.ones(Sq, Sk, dtype=torch.bool)
+    if wr >= 0:
+        vis &= kj <= qi + wr
+    if wl >= 0:
+        vis &= kj >= qi - wl
+    qd, kd, vd = [t.double().requires_grad_(True) for t in (q, k, v)]
+    s = torch.einsum("bqhd,bkhd->bhqk", qd, kd.repeat_interleave(H // Hk, dim=2)) * scale
+    s = s.masked_fill(~vis, float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, -1), nan=0.0)
+    ro = torch.einsum("bhqk,bkhd->bqhd", p, vd.repeat_interleave(H // Hk, dim=2))
+    ro.backward(do.double())
+    out, lse, _, _ = R._flash_attn_forward(q.float(), k.float(), v.float(), 0.0, scale, causal, window[0], window[1])
+    assert (out.double() - ro).abs().max() < 2e-5
+    dq, dk, dv = (torch.empty_like(t, dtype=torch.float32) for t in (q, k, v))
+    R._flash_attn_backward(do.float(), q.float(), k.float(), v.float(), out, lse, dq, dk, dv, 0.0, scale, causal,
+                           window[0], window[1])
+    for got, ref in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
+        assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())

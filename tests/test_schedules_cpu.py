@@ -238,3 +238,80 @@ def test_llama3_fused_equals_unfused_four_groups():
     ret = mgr.dict()
     mp.spawn(_llama3_groups_rank, args=(2, free_port(), ret), nprocs=2, join=True)
     assert ret[0] == [] and ret[1] == [], dict(ret)
+
+
+def _llama3_window_rank(rank, W, port, ret):
+    import os
+    import torch
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle import flash_attn_ref as O
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    g = torch.Generator().manual_seed(78)
+    T, H, Hk, D = 96, 4, 2, 16
+    cu = torch.tensor([0, 20, 61, 96], dtype=torch.int32)
+    q, k, v, do = (torch.randn(T, h, D, generator=g).to(torch.bfloat16) for h in (H, Hk, Hk, H))
+    win = (7, 7)
+    # single-process oracle on the whole packed batch
+    ro, _, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, 0.0, D ** -0.5, True, win[0], win[1])
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, 0.0, D ** -0.5, True, win[0], win[1])
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu, cu, 0, 0, 0.0, D ** -0.5, True, win[0], win[1])
+    L = T // W
+    sl = slice(rank * L, (rank + 1) * L)
+    cq, ck, mq, mk, ks = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, rank, W)
+    ql, kl, vl = (t[sl].clone().requires_grad_(True) for t in (q, k, v))
+    out = R.llama3_flash_attn_varlen_func(ql, kl, vl, cq, ck, mq, mk, heads_k_stride=1, local_k_slice=ks, causal=True,
+                                          window_size=win)
+    out.backward(do[sl])
+    errs = []
+    for name, got, ref in (("out", out, ro[sl]), ("dq", ql.grad, rdq[sl]), ("dk", kl.grad, rdk[sl]), ("dv", vl.grad, rdv[sl])):
+        d = (got.float() - ref.float()).abs().max().item()
+        if d > 3e-2:
+            errs.append(f"{name}: {d:.3e}")
+    # the ring schedules must refuse a window on a multi-rank group (it would be applied per block)
+    try:
+        R.zigzag_ring_flash_attn_func(q[sl].unsqueeze(0), k[sl].unsqueeze(0), v[sl].unsqueeze(0), causal=True, window_size=win)
+        errs.append("zigzag accepted a window on 2 ranks")
+    except NotImplementedError:
+        pass
+    ret[rank] = errs
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_llama3_sliding_window_two_ranks():
+    """llama3 gathers K/V, so a sliding window is well defined on any group (the reference forwards window_size to
+    flash_attn there: llama3_flash_attn_varlen.py:147,282); checked against the single-process oracle"""
+    import torch.multiprocessing as mp
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_llama3_window_rank, args=(2, free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == [] and ret[1] == [], dict(ret)
+
+
+def test_single_rank_window_through_public_api(single_rank_group):
+    import torch
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle import flash_attn_ref as O
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    try:
+        g = torch.Generator().manual_seed(4)
+        qkv = torch.randn(1, 48, 3, 2, 16, generator=g).to(torch.bfloat16).requires_grad_(True)
+        out = R.zigzag_ring_flash_attn_qkvpacked_func(qkv, causal=True, window_size=(5, 0))
+        out.sum().backward()
+        ref, _ = O.full_attention_fp64(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], True, window=(5, 0))
+        assert (out.double() - ref).abs().max() < 2e-2 and qkv.grad is not None
+    finally:
+        backend.set_backend(None)
