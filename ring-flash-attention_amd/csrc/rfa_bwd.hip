@@ -825,8 +825,13 @@ static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
   if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin>(p, stream);
   return launch_dkdv_t<T, 64, false, false, kWin>(p, stream);
 }
+#ifndef RFA_DKDV1
+#define RFA_DKDV1 0          // 1: head-dim-128, window-free calls run the one-wave-per-SIMD kernel of rfa_bwd1.hip
+                             // (measured slower than the 8-wave form, see the header there: kept as an experiment)
+#endif
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
+  if (RFA_DKDV1 && p.D == 128 && !win) return launch_bwd_dkdv1(p, dtype, stream);
   if (p.ds != nullptr && p.D == 128 && !win)      // dS spill instance (rfa_api.cpp only passes ds for eligible calls)
     return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false>(p, stream)
                       : launch_dkdv_t<f16_t, 128, true, true, false>(p, stream);

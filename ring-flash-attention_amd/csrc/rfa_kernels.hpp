@@ -104,6 +104,8 @@ int fwd_qrows_per_block();
 int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream);
+// one-wave-per-SIMD dK/dV kernel (rfa_bwd1.hip): head dim 128 exactly, no window; spills dS when p.ds is set
+int launch_bwd_dkdv1(const BwdParams& p, int dtype, hipStream_t stream);
 // dQ = scale * dS K from the dS blocks a preceding launch_bwd_dkdv (with p.ds set) stored; dense, D == 128
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream);
 constexpr int kDsBlockBytes = 2048;   // one (32 query x 32 key) block of dS in the io dtype
