@@ -140,9 +140,10 @@ typedef struct {
   rfa_strides dq_acc_st, dk_acc_st, dv_acc_st;
   int32_t acc_init;
   /* workspace for dK/dV partials (already summed over the query heads of a K/V group), io dtype,
-   * 2 * total_k*Hk*D elements (rfa_bwd_workspace_bytes).  May be NULL whenever
-   * rfa_bwd_workspace_bytes() returns 0: single-phase calls that write dk/dv, or that overwrite
-   * dk_acc/dv_acc (acc_init or RFA_BWD_KV_OVERWRITE). */
+   * rfa_bwd_workspace_bytes() bytes: 2 * total_k*Hk*D elements, times the number of workgroups that share
+   * a key block's query range when the 256-key kernel form is used (a function of the shapes only).
+   * ALWAYS size it with rfa_bwd_workspace_bytes(); may be NULL whenever that returns 0 (single-phase
+   * calls that write dk/dv or overwrite dk_acc/dv_acc on launches that need no such split). */
   void *workspace;
   const int32_t *cu_seqlens_q, *cu_seqlens_k;
   int32_t q_half, k_half;
@@ -178,7 +179,8 @@ enum {
   /* dk_acc / dv_acc are OVERWRITTEN with this block's dK/dV (fp32) while dq_acc still follows
    * acc_init — for schedules in which every dK/dV accumulator slot receives exactly one block
    * (all-gather / reduce-scatter exchange).  In a single-phase call the dK/dV kernel then stores
-   * fp32 straight into dk_acc / dv_acc: no workspace, no reduction pass. */
+   * fp32 straight into dk_acc / dv_acc: no workspace, no reduction pass (unless the launch is split,
+   * see `workspace`). */
   RFA_BWD_KV_OVERWRITE = 16
 };
 

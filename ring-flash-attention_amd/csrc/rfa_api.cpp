@@ -4,6 +4,8 @@
 #include "../../include/rfa.h"
 #include "rfa_kernels.hpp"
 
+#include <cstdlib>
+
 using namespace rfa;
 
 namespace {
@@ -122,8 +124,37 @@ static bool bwd_single_phase(const rfa_bwd_args* a) {
 static bool bwd_kv_direct(const rfa_bwd_args* a) {
   return a->dk_acc != nullptr && bwd_single_phase(a) && (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE));
 }
+
+// Which dK/dV kernel form a call runs (a pure function of the call's shapes, so that rfa_bwd_workspace_bytes, a
+// BWD_COMPUTE and its BWD_REDUCE call agree): the 256-key workgroup form needs head dim 128 and no window; its
+// workgroups are B * Hk * ceil(Sk / 256), so the Q/dO tile range of a key block is shared by up to 4 workgroups
+// until the launch has about two workgroups per CU (a causal launch needs that many for its heavy-first order to
+// balance), each with at least 8 tiles.  Launches that stay small even so run the 128-key form (twice the
+// workgroups).  RFA_DKDV_WIDE=0 / RFA_DKDV_NSPLIT=n override (tuning).
+struct DkdvPlan { int wide, nsplit; };
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
+  // (read per call: the tests force every form on small shapes)
+  const int env_wide = env_int("RFA_DKDV_WIDE", 1), env_nsplit = env_int("RFA_DKDV_NSPLIT", 0);
+  DkdvPlan pl{0, 1};
+  const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
+  if (!env_wide || a->D != kHeadDim || win) return pl;
+  const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
+  const int64_t wgs = (int64_t)a->B * a->Hk * ((sk + 255) / 256);
+  int ns = 1;
+  while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 512) ++ns;
+  if (env_nsplit > 0) ns = env_nsplit > 8 ? 8 : env_nsplit;
+  if (wgs * ns < 320 && env_nsplit <= 0) return pl;
+  pl.wide = 1;
+  pl.nsplit = ns;
+  return pl;
+}
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
   if (!bwd_single_phase(a)) return true;
+  if (bwd_dkdv_plan(a).nsplit > 1) return true;
   return a->dk_acc != nullptr && !bwd_kv_direct(a);
 }
 
@@ -140,7 +171,7 @@ int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
-  return 2 * a->total_k * (int64_t)a->Hk * a->D * 2;
+  return 2 * a->total_k * (int64_t)a->Hk * a->D * 2 * bwd_dkdv_plan(a).nsplit;
 }
 
 int rfa_bwd(const rfa_bwd_args* a, void* stream) {
@@ -184,21 +215,28 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
   p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();
-  p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block() - 1) / bwd_dkdv_keys_per_block();
+  const DkdvPlan plan = bwd_dkdv_plan(a);
+  p.wide = plan.wide; p.nsplit = plan.nsplit;
+  p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block(plan.wide) - 1) / bwd_dkdv_keys_per_block(plan.wide);
 
   Strides ws_st{};
-  if (bwd_kv_direct(a)) {
+  if (bwd_kv_direct(a) && plan.nsplit == 1) {
     p.dk = a->dk_acc; p.dv = a->dv_acc;
     p.dk_st = cv(a->dk_acc_st); p.dv_st = cv(a->dv_acc_st);
     p.kv_f32 = 1;
   } else if (ws) {
-    // partials: (rows, Hk, D) contiguous; dense rows = b*Sk + row (own batch stride)
+    // partials: (rows, Hk, nsplit, D) contiguous; dense rows = b*Sk + row (own batch stride).  The kernel addresses
+    // K/V head hk of split s at element (hk * nsplit + s) * D of a row, reduce_kernel reads the nsplit entries of
+    // a K/V head as its "group" (G = nsplit, head stride D)
+    const int64_t ns = plan.nsplit;
     ws_st.head = a->D;
-    ws_st.row = (int64_t)a->Hk * a->D;
-    ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->Hk * a->D;
+    ws_st.row = (int64_t)a->Hk * ns * a->D;
+    ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->Hk * ns * a->D;
     p.dk = a->workspace;
-    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->Hk * a->D * 2;
+    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->Hk * ns * a->D * 2;
     p.dk_st = ws_st; p.dv_st = ws_st;
+    p.dk_st.head = p.dv_st.head = ns * a->D;
+    p.kv_split_stride = a->D;
   } else {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
@@ -229,7 +267,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       r.src = which ? p.dv : p.dk;
       r.src_st = ws_st;
       r.cu_k = a->cu_seqlens_k;
-      r.B = a->B; r.Hk = a->Hk; r.G = 1; r.D = a->D; r.Sk = a->Sk;   // groups are already summed
+      r.B = a->B; r.Hk = a->Hk; r.G = plan.nsplit; r.D = a->D; r.Sk = a->Sk;   // query-head groups are already summed
       r.k_half = a->k_half; r.acc_init = kv_init;
       if (a->dk_acc) {
         r.dst_acc = which ? a->dv_acc : a->dk_acc;

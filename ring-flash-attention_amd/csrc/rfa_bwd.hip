@@ -31,8 +31,25 @@
 #ifndef RFA_KV_AHEAD
 #define RFA_KV_AHEAD 2       // dkdv: fragment pairs read this many MFMAs ahead in the S/dP GEMMs (3, 4: +1.5 %)
 #endif
+#ifndef RFA_KV_WIDE_UNROLL
+#define RFA_KV_WIDE_UNROLL 0 // dkdv kWide: 1 = the two sub-tile bodies unrolled, 0 = a runtime loop over one body
+#endif
 #ifndef RFA_KV_AHEAD2
 #define RFA_KV_AHEAD2 2      // dkdv: transpose-read fragment pairs ahead in the dV/dK GEMMs
+#endif
+// measurement-only switches for dkdv_kernel (results are wrong when one is 0): loop cost without the staging loads /
+// the LDS fragment reads / the exp-mask-multiply work / the per-tile wait + barrier
+#ifndef RFA_KV_X_LOAD
+#define RFA_KV_X_LOAD 1
+#endif
+#ifndef RFA_KV_X_LDS
+#define RFA_KV_X_LDS 1
+#endif
+#ifndef RFA_KV_X_VALU
+#define RFA_KV_X_VALU 1
+#endif
+#ifndef RFA_KV_X_SYNC
+#define RFA_KV_X_SYNC 1
 #endif
 #ifndef RFA_KV_PRIO
 #define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral)
@@ -351,16 +368,25 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging) else zero padded (register staging);
 // kSpill: store dS for rfa_dqs.hip (kD = 128 only)
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin>
+// kWide: the workgroup owns 256 keys = 8 key blocks, wave w runs BOTH sub-tiles of every Q/dO tile for key
+// block w.  Same registers per wave as the parity form (one sub-tile is live at a time), same LDS (the V rows
+// take the space the final parity exchange used), but every staged Q/dO tile now feeds twice the MFMAs: the
+// LDS-DMA pieces per MFMA are halved (measured: dropping half of the pieces is worth 15 % of the kernel),
+// one barrier per 128 MFMAs per SIMD instead of 64, no exchange at the end.  256-key workgroups are too few for
+// a causal launch at Hk = 8, so the tile range of a key block can be split over p.nsplit workgroups whose
+// partials (io dtype, workspace) are summed by reduce_kernel (rfa_api.cpp).
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   static_assert(!kSpill || (kD == 128 && !kWin), "the dS spill path: head dim 128, no window");
+  static_assert(!kWide || (kD == 128 && kFullD && !kWin), "the 256-key form: head dim 128, no window");
+  constexpr int kKeys = kWide ? 2 * kKvKeys : kKvKeys;       // keys per workgroup
   typedef HeadGeo<kD> Geo;
   constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
   constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
   constexpr int kKvTileBytes = kKvQ * kRowBytes;             // 16 KiB (8 KiB at kD = 64)
-  constexpr int kKvKvBytes = kKvKeys * kRowBytes;            // 32 KiB (16 KiB) per K / V tile
+  constexpr int kKvKvBytes = kKvKeys * kRowBytes;            // 32 KiB (16 KiB) per 128 keys
   constexpr int kChunks = kD / 8;
   constexpr int kRowsPerPass = kKvThreads / kChunks;         // register staging: one chunk per thread and pass
   constexpr int kPasses = kKvQ / kRowsPerPass;               // passes (= 1 KiB DMA pieces per wave) per Q / dO tile
@@ -370,15 +396,15 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // compile-time immediate — no vector address arithmetic beside the swizzle XORs.
   constexpr int kOffDo = 2 * kKvTileBytes;            // dO = Q + 32K  (immediate)
   constexpr int kOffV = 4 * kKvTileBytes;             // 64K
-  constexpr int kOffStat = kOffV + 2 * kKvKvBytes;    // 128K (96K..128K is only used by the final exchange)
+  constexpr int kOffStat = kOffV + 2 * kKvKvBytes;    // 128K (96K..128K: the final parity exchange / V rows 128..255 of kWide)
   lds_t* vtile = smem + kOffV;                        // [128 keys][128] swizzled
 
   if (lds_addr(smem) & 0xffff) __builtin_trap();     // address XOR tricks below need a 64 KiB-aligned block
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kbw = wave & 3;
-  const int par = wave >> 2;
+  const int kbw = kWide ? wave : (wave & 3);
+  const int par = kWide ? 0 : (wave >> 2);
   const int g = lane >> 5;
   const int l31 = lane & 31;
 
@@ -386,6 +412,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int G = p.H / p.Hk;
   const int hk = idx % p.Hk;
   idx /= p.Hk;
+  const int nsplit = kWide ? p.nsplit : 1;
+  const int qsplit = idx % nsplit;                    // which part of the key block's tile range
+  idx /= nsplit;
   const int kblk = idx % p.nkblk;
   const int b = idx / p.nkblk;
   const int h0 = hk * G;                              // the G query heads h0 .. h0+G-1 share this K/V head
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
   const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
   const int lq = qs.len, lk = ks.len;
-  const int kwg0 = kblk * kKvKeys;
+  const int kwg0 = kblk * kKeys;
   if (kwg0 >= lk) return;
   const int off = lk - lq;
   const int kw0 = kwg0 + kbw * 32;
@@ -419,11 +448,16 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (qfirst < 0) qfirst = 0;
   }
   int qlast = lq;                              // exclusive
-  if (lo && kwg0 + kKvKeys - off + wl < qlast) qlast = kwg0 + kKvKeys - off + wl;
-  const int jt0 = qfirst / kKvQ;
+  if (lo && kwg0 + kKeys - off + wl < qlast) qlast = kwg0 + kKeys - off + wl;
+  int jt0 = qfirst / kKvQ;
   int jt1 = (qlast + kKvQ - 1) / kKvQ;         // exclusive
   if (jt1 <= jt0) jt1 = jt0;                   // nothing visible: no tiles (the unconditional prologue fetch below
                                                // then reads tile jt0 - 1 >= -1: clamped to 0 there)
+  if (nsplit > 1) {                            // this workgroup's share of the tiles (may be empty: it stores zeros)
+    const int n = jt1 - jt0, first = jt0;
+    jt0 = first + (int)((int64_t)n * qsplit / nsplit);
+    jt1 = first + (int)((int64_t)n * (qsplit + 1) / nsplit);
+  }
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
@@ -432,7 +466,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // ---- V rows of the workgroup go to LDS once (128 rows x kChunks chunks); this wave's
   // K rows stay in registers as the B operand of the S GEMM (4 kNK registers)
 #pragma unroll
-  for (int i = 0; i < kKvKeys / kRowsPerPass; ++i) {
+  for (int i = 0; i < kKeys / kRowsPerPass; ++i) {
     const int row = sr + kRowsPerPass * i;
     int kr = kwg0 + row;
     kr = kr < lk ? kr : lk - 1;
@@ -466,7 +500,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // group c = wave + 8 i lands in row 4c + L/16, physical chunk L%16 and must FETCH the logical chunk
   // that the swizzle puts there.  Otherwise (D < 128) the chunks beyond D have to be zeroed, which
   // needs the register path.
-  constexpr bool kDma = kFullD;
+#ifndef RFA_KV_DMA
+#define RFA_KV_DMA 1
+#endif
+  constexpr bool kDma = kFullD && RFA_KV_DMA;
   int voff_q[kPasses], voff_do[kPasses];
 #pragma unroll
   for (int i = 0; i < kPasses; ++i) {
@@ -486,9 +523,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // workgroup: 3.5x the fabric traffic, measured.)
   int ld_g = 0, ld_j = jt1 > 0 ? jt1 - 1 : 0;         // (head in group, tile) the next load_tile() fetches
   auto load_tile = [&]() {
-    const int j = ld_j;
-    const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
-    const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
+    const int j = RFA_KV_X_LOAD == 2 ? 0 : ld_j;       // (2: measurement, every load hits the same hot tile)
+    const T* qbase = qbase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.q_st.head;
+    const T* dobase = dobase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.dout_st.head;
     const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
     const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
     if (++ld_g >= G) {
@@ -508,7 +545,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       if (kDma) {
         const int dst = lds_addr(smem) + dma_stage + (wave + kKvWaves * i) * 1024;
         dma_load128(dq_, dst, voff_q[i]);
-        dma_load128(ddo, dst + kOffDo, voff_do[i]);
+        if (RFA_KV_X_LOAD != 3) dma_load128(ddo, dst + kOffDo, voff_do[i]);      // (3: measurement, Q only)
       } else {
         qreg[i] = buffer_load128<T>(rq, voff_q[i]);
         doreg[i] = buffer_load128<T>(rdo, voff_do[i]);
@@ -567,7 +604,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int ds_nkb = (lk + 31) >> 5;
   const int64_t ds_head_bytes = (int64_t)((lq + 31) >> 5) * ds_nkb * kDsBlockBytes;
   const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
-  const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * 4 + kbw);
+  const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kKeys / 32) + kbw);
 
   const float c = p.scale * kLog2e;
   f32x16 dk[kNB], dv[kNB];
@@ -584,18 +621,29 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   ws ^= kKvStatBytes;
   __syncthreads();
 
-  const int t = par;                                  // this wave's sub-tile of every Q tile
 #if RFA_KV_PRIO
   if (par == 0) __builtin_amdgcn_s_setprio(2);
 #endif
   const int ntile = jt1 > jt0 ? (jt1 - jt0) * G : 0;
   int j = jt1 - 1, cg = 0;
   for (int f = 0; f < ntile; ++f) {
-    if (f + 1 < ntile) load_tile();
+    if (RFA_KV_X_LOAD && f + 1 < ntile) load_tile();
+    int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
+    bool active = false;
+    // parity form: the one sub-tile t = par; kWide: both, one after the other (the sub-tile lives in address
+    // bit 13 of the Q/dO fragment bases and bit 7 of the statistics base: toggled, not re-computed)
+#if RFA_KV_WIDE_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int t0 = 0; t0 < (kWide ? 2 : 1); ++t0) {
+    const int t = kWide ? t0 : par;
     const int qs0 = j * kKvQ + 32 * t;
-    const bool active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) &&
-                        !(lo && qs0 + off - wl > kw0 + 31);
+    active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) &&
+             !(lo && qs0 + off - wl > kw0 + 31);
     if (active) {
+      ++nact;
       f32x16 s, dp;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]: 4 LDS reads, no VALU
@@ -609,8 +657,14 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         constexpr int kAhead = RFA_KV_AHEAD;
         constexpr int kN = 2 * kNK;
         vec8<T> a[kN], w[kNK];
-        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0)); };
-        auto fw = [&](int i) { return lds_read128<T>(lds_ptr(avp ^ (i << 5))); };
+        auto fa = [&](int i) {
+          if (!RFA_KV_X_LDS) return kwr[i % kNK];
+          return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0));
+        };
+        auto fw = [&](int i) {
+          if (!RFA_KV_X_LDS) return kwr[i];
+          return lds_read128<T>(lds_ptr(avp ^ (i << 5)));
+        };
 #pragma unroll
         for (int i = 0; i < kAhead; ++i) { a[i] = fa(i); w[i] = fw(i); }
 #pragma unroll
@@ -645,8 +699,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, l2v[jj][e]));
-      if (need_mask) {
+          if (RFA_KV_X_VALU) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, l2v[jj][e]));
+      if (RFA_KV_X_VALU && need_mask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = qs0 + crow(r, g);
@@ -657,7 +711,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dp[4 * jj + e] *= s[4 * jj + e];
+        for (int e = 0; e < 4; ++e)
+          if (RFA_KV_X_VALU) dp[4 * jj + e] *= s[4 * jj + e];
       {
         const vec8<T> pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 8);
         const vec8<T> ds0 = pack8<T>(dp, 0), ds1 = pack8<T>(dp, 8);
@@ -683,6 +738,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
           constexpr int kPer = Geo::kSwzRows;
           const int kv = (16 * ks2 % kPer) / 16;
           const int imm = (which ? 0 : kOffDo) + (16 * ks2 / kPer) * kPer * kRowBytes;
+          if (!RFA_KV_X_LDS) return kwr[i % kNK];
           vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[kv][0] ^ (dblk << 6)) + imm);
           vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[kv][1] ^ (dblk << 6)) + imm);
           return concat<T>(lo, hi);
@@ -708,10 +764,24 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         if (RFA_SPILL_PROBE == 2) spill();
       }
     }
+    if (kWide) {
+      aq ^= 32 * kRowBytes;
+#pragma unroll
+      for (int kv = 0; kv < kTK; ++kv) {
+        tq[kv][0] ^= 32 * kRowBytes;
+        tq[kv][1] ^= 32 * kRowBytes;
+      }
+      sa ^= 32 * 4;
+    }
+    }   // sub-tile loop
     // The DMA (and the row statistics) of tile j+1 must have landed before they are published.  vmcnt counts
     // stores too and retires in issue order: the two dS spill stores of this sub-tile are the youngest
     // operations and stay in flight (draining them costs a store round trip per tile: 0.93 -> 1.2 ms)
-    if (kSpill && active && RFA_SPILL_PROBE != 1 && RFA_SPILL_PROBE != 3) wait_vmem<2>();
+    if (!RFA_KV_X_SYNC) {
+    } else if (kWide && kSpill && nact == 2) wait_vmem<4>();
+    else if (kWide && kSpill && nact == 1) wait_vmem<2>();
+    else if (kWide) wait_all_vmem();
+    else if (kSpill && active && RFA_SPILL_PROBE != 1 && RFA_SPILL_PROBE != 3) wait_vmem<2>();
     else if (kSpill && active && RFA_SPILL_PROBE == 3) wait_vmem<1>();
     else wait_all_vmem();
     load_landed(statreg);
@@ -729,13 +799,13 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     sa ^= kKvStatBytes;
     wq ^= kKvTileBytes;
     ws ^= kKvStatBytes;
-    __syncthreads();
+    if (RFA_KV_X_SYNC) __syncthreads();
   }
 
   // ---- combine the two parities: parity 1 hands over its dK^T partial, parity 0 its dV^T partial
   // (fp32, [kb][dblk][r][lane] so that the partner lane reads exactly what its twin wrote); the K/V
   // tiles and the Q/dO buffers (128 KiB, contiguous) are dead by now and take the 2 x 64 KiB of partials.
-  {
+  if (!kWide) {
     float* xbuf = (float*)smem_raw;                    // generic pointer into LDS
     constexpr int kXW = kNB * 1024;                    // floats per key block and tensor (4 kb per tensor: 2 x 64 KiB at kD = 128)
     const int slot = (par == 1 ? 0 : 4 * kXW) + kbw * kXW;
@@ -755,35 +825,34 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 
   if (krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
-  if (p.kv_f32) {
-    // fp32 store straight into the caller's accumulator slot (overwrite): lane (key, g) holds, per
-    // (dblk, jj), the 4 consecutive columns 32 dblk + 8 jj + 4 g .. +3
-    const f32x16(&fin)[kNB] = (par == 0) ? dk : dv;
-    const float sc_ = (par == 0) ? p.scale : 1.f;
-    const int64_t sb = (par == 0) ? p.dk_st.batch : p.dv_st.batch;
-    const int64_t sr_ = (par == 0) ? p.dk_st.row : p.dv_st.row;
-    const int64_t sh = (par == 0) ? p.dk_st.head : p.dv_st.head;
-    float* ob = (float*)((par == 0) ? p.dk : p.dv) + kbatch * sb + orow * sr_ + (int64_t)hk * sh;
+  // parity form: parity 0 stores dK, parity 1 dV; kWide: this wave stores both (which = 0: dK, 1: dV)
+  const int64_t soff = (int64_t)qsplit * p.kv_split_stride;      // this split's partial (elements; 0 without a split)
 #pragma unroll
-    for (int dblk = 0; dblk < kNB; ++dblk)
+  for (int which = 0; which < 2; ++which) {
+    if (!kWide && which != par) continue;
+    const f32x16(&fin)[kNB] = which ? dv : dk;
+    const float sc_ = which ? 1.f : p.scale;
+    const Strides st = which ? p.dv_st : p.dk_st;
+    const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head + soff;
+    if (p.kv_f32) {
+      // fp32 store straight into the caller's accumulator slot (overwrite): lane (key, g) holds, per
+      // (dblk, jj), the 4 consecutive columns 32 dblk + 8 jj + 4 g .. +3
+      float* ob = (float*)(which ? p.dv : p.dk) + eoff;
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int d0 = 32 * dblk + 8 * jj + 4 * g;
-        if (kFullD || d0 < p.D) {
-          f32x4 x;
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
-          *(f32x4*)(ob + d0) = x;
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (kFullD || d0 < p.D) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+            *(f32x4*)(ob + d0) = x;
+          }
         }
-      }
-    return;
-  }
-  if (par == 0) {
-    T* dkb = (T*)p.dk + kbatch * p.dk_st.batch + orow * p.dk_st.row + (int64_t)hk * p.dk_st.head;
-    store_rows16<T, kFullD, kNB>(dkb, dk, p.scale, g, p.D, true);
-  } else {
-    T* dvb = (T*)p.dv + kbatch * p.dv_st.batch + orow * p.dv_st.row + (int64_t)hk * p.dv_st.head;
-    store_rows16<T, kFullD, kNB>(dvb, dv, 1.f, g, p.D, true);
+    } else {
+      store_rows16<T, kFullD, kNB>((T*)(which ? p.dv : p.dk) + eoff, fin, sc_, g, p.D, true);
+    }
   }
 }
 
@@ -797,13 +866,14 @@ static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin>
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin>, kv_smem<kD>(), attr_done)) return rc;
-  const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B;      // one workgroup per (key block, K/V head)
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide>, kv_smem<kD>(), attr_done)) return rc;
+  // one workgroup per (key block, K/V head) [x tile-range split of the 256-key form]
+  const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B * (kWide ? p.nsplit : 1);
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
@@ -832,6 +902,13 @@ static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
   if (RFA_DKDV1 && p.D == 128 && !win) return launch_bwd_dkdv1(p, dtype, stream);
+  if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 without a window
+    if (p.ds != nullptr)
+      return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true>(p, stream)
+                        : launch_dkdv_t<f16_t, 128, true, true, false, true>(p, stream);
+    return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, false, false, true>(p, stream)
+                      : launch_dkdv_t<f16_t, 128, true, false, false, true>(p, stream);
+  }
   if (p.ds != nullptr && p.D == 128 && !win)      // dS spill instance (rfa_api.cpp only passes ds for eligible calls)
     return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false>(p, stream)
                       : launch_dkdv_t<f16_t, 128, true, true, false>(p, stream);
@@ -839,6 +916,6 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   return dtype == 0 ? launch_dkdv_d<bf16_t, false>(p, stream) : launch_dkdv_d<f16_t, false>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
-int bwd_dkdv_keys_per_block() { return kKvKeys; }
+int bwd_dkdv_keys_per_block(bool wide) { return wide ? 2 * kKvKeys : kKvKeys; }
 
 }  // namespace rfa

@@ -30,6 +30,9 @@
 
 namespace rfa {
 
+#ifndef RFA_FWD_X_LOAD
+#define RFA_FWD_X_LOAD 1
+#endif
 #ifndef RFA_FWD_WAVES
 #define RFA_FWD_WAVES 8      // waves per workgroup (32 q rows each); 4 -> two independent workgroups per CU
 #endif
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
       for (int i = 0; i < kFwdShare; ++i) {
         const int dst = lds_addr(smem) + kStage * kFwdTileBytes + (wave + kFwdWaves * i) * 1024;
-        dma_load128(rk, dst, voff_k[i]);
-        dma_load128(rv, dst + kFwdStages * kFwdTileBytes, voff_v[i]);
+        if (RFA_FWD_X_LOAD) dma_load128(rk, dst, voff_k[i]);                      // (RFA_FWD_X_LOAD: measurement only,
+        if (RFA_FWD_X_LOAD == 1) dma_load128(rv, dst + kFwdStages * kFwdTileBytes, voff_v[i]);   //  0 no tile loads, 2 K only)
       }
     } else {
       const buf_rsrc_t rk = make_rsrc(kt, nk), rv = make_rsrc(vt, nv);

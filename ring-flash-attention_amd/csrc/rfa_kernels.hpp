@@ -75,6 +75,10 @@ struct BwdParams {
   void* ds;            // dS spill scratch (rfa_dqs.hip) or nullptr: dkdv_kernel stores its packed dS blocks there
   int nqblk, nkblk;
   float scale;
+  // 256-key dK/dV form (dkdv_kernel kWide): the tile range of a key block is shared by nsplit workgroups; split s
+  // stores its partial kv_split_stride elements behind split 0's (rfa_api.cpp lays them out for reduce_kernel)
+  int wide, nsplit;
+  int64_t kv_split_stride;
 };
 
 // dst[b, row, hk, :] (=|+=) sum_g src[b, row, hk*G+g, :]
@@ -110,7 +114,7 @@ int launch_bwd_dkdv1(const BwdParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream);
 constexpr int kDsBlockBytes = 2048;   // one (32 query x 32 key) block of dS in the io dtype
 int bwd_dq_rows_per_block();
-int bwd_dkdv_keys_per_block();
+int bwd_dkdv_keys_per_block(bool wide);
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);
 int launch_merge(const MergeParams& p, int dtype, hipStream_t stream);
 int launch_cast(void* dst, const float* src, int64_t n, int dtype, hipStream_t stream);

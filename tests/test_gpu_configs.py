@@ -102,6 +102,23 @@ def test_config4_zigzag_varlen_w8_gqa_all_heads():
     _run_and_compare(dict(kind="zigzag_varlen", W=8, cu=[0, 1024, 10240, 32768], H=4, Hk=2, D=128, seed=114))
 
 
+@pytest.mark.parametrize("kind,nsplit", [("zigzag", "2"), ("zigzag_varlen", "3"), ("ring", "2")])
+def test_schedules_on_the_forced_256_key_dkdv_form(monkeypatch, kind, nsplit):
+    """every ring step kind (halves, packed halves, two-phase accumulate) with the 256-key dK/dV kernel form and a
+    query-range split forced onto these reduced shapes (production picks the form from the shapes)"""
+    monkeypatch.setenv("RFA_DKDV_NSPLIT", nsplit)
+    if kind == "zigzag":
+        cfg = dict(kind="zigzag", W=4, B=1, S=4096, H=4, Hk=2, D=128, seed=123)
+    elif kind == "zigzag_varlen":
+        cfg = dict(kind="zigzag_varlen", W=2, cu=[0, 512, 2560, 4096], H=4, Hk=2, D=128, seed=124)
+    else:
+        cfg = dict(kind="ring", W=2, B=2, S=2048, H=4, Hk=4, D=128, causal=True, seed=125)
+    for mode in ("gather", "ring") if kind == "zigzag" else (None,):
+        if mode:
+            monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
+        _run_and_compare(cfg)
+
+
 def test_config3_zigzag_w4_gqa_reduced():
     """headline schedule at world_size 4 (S=2048/rank), GQA 8:2 — exercises every zigzag step kind
     with the fused merge / two-phase backward on real kernels at multi-tile sizes."""

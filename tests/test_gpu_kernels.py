@@ -100,10 +100,15 @@ def test_dense_qkvpacked_reference_fixture(single_rank_group, monkeypatch, api, 
     _grads_ok(api, (x.grad[:, :, 0], x.grad[:, :, 1], x.grad[:, :, 2]), (dq, dk, dv))
 
 
+@pytest.mark.parametrize("nsplit", [None, "2"])
 @pytest.mark.parametrize("api,cu", [("zigzag", [0, 128, 1248, 4240]), ("ring", [0, 120, 1248, 4232])])
-def test_varlen_reference_fixture(single_rank_group, api, cu):
-    """reference test/test_{zigzag_,}ring_flash_attn_varlen_func.py at world_size 1 (H=5, D=128)."""
+def test_varlen_reference_fixture(single_rank_group, monkeypatch, api, cu, nsplit):
+    """reference test/test_{zigzag_,}ring_flash_attn_varlen_func.py at world_size 1 (H=5, D=128); nsplit: the
+    256-key dK/dV form forced onto this small shape (csrc/rfa_api.cpp bwd_dkdv_plan)."""
     import ring_flash_attn as R
+
+    if nsplit:
+        monkeypatch.setenv("RFA_DKDV_NSPLIT", nsplit)
 
     dev = _dev()
     g = torch.Generator().manual_seed(43)
@@ -301,6 +306,81 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
         _check(f"spill={spill}.dq_acc", dqa - 3.0, rdq, 1e-2, 2e-2)
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
     _check("dq spill vs recompute", res[True][0], res[False][0].float(), 1e-2, 2e-2)
+
+
+@pytest.mark.parametrize("nsplit", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk", [
+    (700, 700, True, 2, 4, 2),        # ragged tails, GQA, batch: key blocks of 256 with a 188-key tail
+    (1000, 488, True, 1, 4, 1),       # more queries than keys; splits that receive no tile at all store zeros
+    (512, 1024, False, 1, 2, 2),      # ring "front" step shape
+    (96, 300, True, 1, 2, 2),         # fewer tiles (2) than splits
+])
+def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, causal, B, H, Hk):
+    """The 256-key dK/dV kernel form (csrc/rfa_bwd.hip kWide), forced onto small shapes with every split count
+    (RFA_DKDV_NSPLIT; production picks it from the shapes): plain io outputs, fp32 accumulate (+=), fp32
+    overwrite slots, two-phase COMPUTE / REDUCE — with and without the dS spill — against the CPU oracle, and
+    against the 128-key form on the same inputs."""
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn import _C
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, Sq, H, 128, generator=g).to(BF)
+    k = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
+    v = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
+    do = torch.randn(B, Sq, H, 128, generator=g).to(BF)
+    scale = 128 ** -0.5
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, causal)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out = torch.empty_like(qd)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    kw = dict(softmax_scale=scale, causal=causal)
+
+    def run_all():
+        res = {}
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq=dq, dk=dk, dv=dv, **kw)
+        res["plain"] = (dq, dk, dv)
+        dqa = torch.zeros((B, Sq, H, 128), dtype=torch.float32, device=dev)
+        dka = torch.full((B, Sk, Hk, 128), 2.0, dtype=torch.float32, device=dev)
+        dva = torch.full_like(dka, -1.0)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, **kw)          # += (workspace)
+        res["acc"] = (dqa, dka - 2.0, dva + 1.0)
+        dqa = torch.zeros_like(dqa)
+        dka = torch.full_like(dka, 5.0)
+        dva = torch.full_like(dka, 5.0)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, acc_init=True,
+               phases=_C.BWD_KV_OVERWRITE, **kw)                                                 # fp32 slots
+        res["overwrite"] = (dqa, dka, dva)
+        dqa = torch.zeros_like(dqa)
+        dka = torch.full_like(dka, 1.0)
+        dva = torch.full_like(dka, 1.0)
+        part = be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, phases=_C.BWD_COMPUTE, **kw)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, phases=_C.BWD_REDUCE,
+               partials=part, **kw)
+        res["two_phase"] = (dqa, dka - 1.0, dva - 1.0)
+        return res
+
+    monkeypatch.setenv("RFA_DKDV_WIDE", "0")
+    monkeypatch.delenv("RFA_DKDV_NSPLIT", raising=False)
+    narrow = run_all()
+    monkeypatch.setenv("RFA_DKDV_WIDE", "1")
+    monkeypatch.setenv("RFA_DKDV_NSPLIT", nsplit)
+    for spill in ("1", "0"):
+        monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
+        wide = run_all()
+        for mode, got in wide.items():
+            _grads_ok(f"nsplit={nsplit} spill={spill} {mode}", got, (rdq, rdk, rdv))
+            for n, a_, b_ in zip(("dk", "dv"), got[1:], narrow[mode][1:]):      # same math, other summation order
+                _check(f"nsplit={nsplit} spill={spill} {mode}.{n} vs 128-key form", a_, b_.float(), 2e-2, 1e-2)
 
 
 def test_torch_compile_fullgraph_on_gpu(single_rank_group):
