@@ -243,8 +243,15 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    # RFA_BENCH_FORCE_RCCL=1 (tests/test_gpu_rccl_world1.py): a ONE-rank RCCL group with the schedule forced onto its
+    # multi-step path — this script's N > 1 branches (RCCL barrier / all_reduce, fixed-count spin-up, comm block)
+    # on a one-GPU box.  The line it prints is marked and is not a measurement.
+    forced = world == 1 and os.environ.get("RFA_BENCH_FORCE_RCCL") == "1"
+    if forced:
+        os.environ["RFA_TEST_FORCE_STEPS"] = "1"
+    multi = world > 1 or forced
     try:
-        if world > 1:
+        if multi:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=0, world_size=1)
@@ -314,7 +321,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev if world > 1 else "cpu")
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev if multi else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return tmax.item()
 
@@ -322,7 +329,7 @@ def main():
     # its idle clocks; without it the W warm-up steps (W x ~2 ms) end while the clocks are still ramping and
     # the timed region measures the ramp, not the kernels.  Untimed, bounded, reported in the JSON line.
     spin_s = float(os.environ.get("RFA_BENCH_SPINUP_S", "0.3"))
-    if world == 1:
+    if not multi:
         t_spin = time.perf_counter()
         while spin_s > 0 and time.perf_counter() - t_spin < spin_s:
             step()
@@ -370,7 +377,9 @@ def main():
     }
 
     # ---- exchange accounting (N > 1): the same rank-local kernel sequence with the exchange looped back
-    if world > 1:
+    if forced:
+        result["forced_rccl_world1"] = "N > 1 code path on a one-rank RCCL group (test only, not a measurement)"
+    if multi:
         mode = exchange_mode(kv.detach()[:, :, 0], world) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
         rfa_utils.set_loopback((rank, world))
         try:

@@ -4,13 +4,13 @@ def _prep_qkv(q, k, v, group):
     """Kernels take strided views (last stride 1, 16-byte aligned rows).  K/V only have to be
     contiguous when they travel (world_size > 1: they are RCCL send buffers), so the packed
     `kv[:, :, 0]` views of the benchmark are not copied on a single GPU."""
-    from .utils import group_rank_world
-    world = group_rank_world(group)[1]
+    from .utils import group_rank_world, single_rank
+    travels = not single_rank(group_rank_world(group)[1])
     if q.stride(-1) != 1:
         q = q.contiguous()
-    if world > 1 or k.stride(-1) != 1:
+    if travels or k.stride(-1) != 1:
         k = k.contiguous()
-    if world > 1 or v.stride(-1) != 1:
+    if travels or v.stride(-1) != 1:
         v = v.contiguous()
     return q, k, v
 

@@ -27,7 +27,7 @@ import os
 import torch
 
 from .backend import get_backend
-from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async
+from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async, single_rank
 from ._api import _check_unsupported, _opaque
 from ._common import _as_cu
 
@@ -128,7 +128,7 @@ def llama3_flash_attn_varlen_forward(
     lse = torch.empty((nheads, T), dtype=torch.float32, device=q.device)
     world_size = group_rank_world(process_group)[1]
 
-    if world_size == 1:
+    if single_rank(world_size):
         be.fwd(q, k[local_k_slice], v[local_k_slice], softmax_scale=softmax_scale, causal=causal,
                out=out, lse=lse, window=window_size, **vl)
         return out, lse
@@ -199,7 +199,7 @@ def llama3_flash_attn_varlen_backward(
     dv = torch.empty_like(v)
     world_size = group_rank_world(process_group)[1]
 
-    if world_size == 1:
+    if single_rank(world_size):
         if local_k_slice.start != 0 or local_k_slice.stop != total_k:
             dk.zero_()
             dv.zero_()

@@ -11,7 +11,7 @@ import torch
 
 from . import _C
 from .backend import get_backend
-from .utils import RingComm
+from .utils import RingComm, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 
 
@@ -34,7 +34,7 @@ def stripe_flash_attn_forward(
     comm = RingComm(process_group)
     B, S, H, D = q.shape
 
-    if comm.world_size == 1:
+    if single_rank(comm.world_size):
         out = torch.empty_like(q)
         lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size)
@@ -92,7 +92,7 @@ def stripe_flash_attn_backward(
     delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
     be.bwd_preprocess(dout, out, delta)
 
-    if kv_comm.world_size == 1:
+    if single_rank(kv_comm.world_size):
         dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size)

@@ -15,6 +15,7 @@ same method names and error behaviour, re-designed for RCCL over xGMI:
   eager TorchScript ops; the schedules in this package do not even call it — they use the
   merge fused into the attention epilogue — it is kept for API parity.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -106,6 +107,13 @@ _LOOPBACK = None
 def set_loopback(rank_world=None):
     global _LOOPBACK
     _LOOPBACK = rank_world
+
+
+def single_rank(world_size: int) -> bool:
+    """True when a schedule may collapse to its single-kernel form.  RFA_TEST_FORCE_STEPS=1 (tests only:
+    tests/test_gpu_rccl_world1.py) keeps the multi-step code path — exchange buffers, collectives, side stream,
+    fp32 accumulators — even on a one-rank group, which is how the RCCL calls get exercised on a one-GPU box."""
+    return world_size == 1 and os.environ.get("RFA_TEST_FORCE_STEPS", "0") != "1"
 
 
 def group_rank_world(process_group):

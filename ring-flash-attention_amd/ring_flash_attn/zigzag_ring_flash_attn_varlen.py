@@ -17,7 +17,7 @@ import torch
 
 from . import _C
 from .backend import get_backend, HALF_FRONT, HALF_BACK
-from .utils import RingComm
+from .utils import RingComm, single_rank
 from ._api import make_autograd_function, make_varlen_api
 
 
@@ -77,7 +77,7 @@ def zigzag_ring_flash_attn_varlen_forward(
     T, H, D = q.shape
     vl = dict(cu_seqlens_q=cu_seqlens, cu_seqlens_k=cu_seqlens, max_seqlen_q=max_seqlen, max_seqlen_k=max_seqlen)
 
-    if comm.world_size == 1:
+    if single_rank(comm.world_size):
         out = torch.empty_like(q)
         lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size, **vl)
@@ -138,7 +138,7 @@ def zigzag_ring_flash_attn_varlen_backward(
     delta = torch.empty((H, T), dtype=torch.float32, device=q.device)
     be.bwd_preprocess(dout, out, delta, cu_seqlens_q=cu_seqlens, max_seqlen_q=max_seqlen)
 
-    if kv_comm.world_size == 1:
+    if single_rank(kv_comm.world_size):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, **vl)

@@ -1,0 +1,108 @@
+"""Worker of tests/test_gpu_rccl_world1.py: ONE process, ONE GPU, process group backend "nccl" (= RCCL) with
+world_size 1, RFA_TEST_FORCE_STEPS=1 — every schedule then runs its multi-step code path (exchange buffers,
+RCCL all_gather / all_to_all / reduce_scatter / batched isend+irecv to itself, the side stream, fp32
+accumulators, final casts) instead of collapsing to one kernel.  At world size 1 the result must equal plain
+attention over the local sequence, which the CPU oracle provides.  This is the only place a one-GPU box can
+execute the RCCL calls of the product path (gloo, used by the multi-rank parity tests, stages through the host)."""
+import os
+import sys
+
+os.environ["RFA_TEST_FORCE_STEPS"] = "1"
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ring-flash-attention_amd"))
+
+import torch
+import torch.distributed as dist
+
+BF = torch.bfloat16
+
+
+def check(name, got, ref, atol, rtol=0.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: {got.shape} vs {ref.shape}"
+    diff = (got - ref).abs().max().item()
+    lim = atol + rtol * ref.abs().max().item()
+    assert diff <= lim, f"{name}: max|err| {diff:.3e} > {lim:.3e}"
+
+
+def main(port):
+    from oracle import flash_attn_ref as O
+    import ring_flash_attn as R
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    g = torch.Generator().manual_seed(5)
+    H, Hk, D, S = 4, 2, 128, 1024
+    scale = D ** -0.5
+
+    def dense_case(fn, name, causal=True, B=2):
+        q = torch.randn(B, S, H, D, generator=g).to(BF)
+        k = torch.randn(B, S, Hk, D, generator=g).to(BF)
+        v = torch.randn(B, S, Hk, D, generator=g).to(BF)
+        do = torch.randn(B, S, H, D, generator=g).to(BF)
+        ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, causal)
+        rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, causal)
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        out, lse, _ = fn(qd, kd, vd, causal=causal, return_attn_probs=True)
+        out.backward(do.to(dev))
+        torch.cuda.synchronize()
+        check(name + ".out", out, ro, 2e-2)
+        check(name + ".lse", lse, rl, 1e-3)
+        for n, a, b in (("dq", qd.grad, rdq), ("dk", kd.grad, rdk), ("dv", vd.grad, rdv)):
+            check(f"{name}.{n}", a, b, 1e-2, 2e-2)
+        print("ok", name, flush=True)
+
+    for mode in ("gather", "ring"):
+        os.environ["RFA_ZIGZAG_EXCHANGE"] = mode
+        for wire in ("io", "fp32"):
+            os.environ["RFA_DKV_WIRE"] = wire
+            dense_case(R.zigzag_ring_flash_attn_func, f"zigzag[{mode},{wire}]")
+    os.environ.pop("RFA_ZIGZAG_EXCHANGE"); os.environ.pop("RFA_DKV_WIRE")
+    dense_case(R.ring_flash_attn_func, "ring.causal")
+    dense_case(R.ring_flash_attn_func, "ring.full", causal=False)
+    dense_case(R.stripe_flash_attn_func, "stripe")
+
+    cu = torch.tensor([0, 128, 640, 1024], dtype=torch.int32)
+    T = int(cu[-1])
+    maxlen = int((cu[1:] - cu[:-1]).max())
+
+    def varlen_case(fn, name, llama3=False):
+        q = torch.randn(T, H, D, generator=g).to(BF)
+        k = torch.randn(T, Hk, D, generator=g).to(BF)
+        v = torch.randn(T, Hk, D, generator=g).to(BF)
+        do = torch.randn(T, H, D, generator=g).to(BF)
+        ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, maxlen, maxlen, 0.0, scale, True)
+        rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu, cu, maxlen, maxlen, 0.0, scale, True)
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        if llama3:
+            cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, causal=True, rank=0, world_size=1)
+            out, lse, _ = fn(qd, kd, vd, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=1, local_k_slice=sl,
+                             causal=True, return_attn_probs=True)
+        else:
+            out, lse, _ = fn(qd, kd, vd, cu.to(dev), maxlen, causal=True, return_attn_probs=True)
+        out.backward(do.to(dev))
+        torch.cuda.synchronize()
+        check(name + ".out", out, ro, 2e-2)
+        check(name + ".lse", lse, rl, 1e-3)
+        for n, a, b in (("dq", qd.grad, rdq), ("dk", kd.grad, rdk), ("dv", vd.grad, rdv)):
+            check(f"{name}.{n}", a, b, 1e-2, 2e-2)
+        print("ok", name, flush=True)
+
+    varlen_case(R.zigzag_ring_flash_attn_varlen_func, "zigzag_varlen")
+    varlen_case(R.ring_flash_attn_varlen_func, "ring_varlen")
+    varlen_case(R.llama3_flash_attn_varlen_func, "llama3", llama3=True)
+    os.environ["RFA_LLAMA3_GATHER_MAX_BYTES"] = "0"          # one K/V head group per collective
+    varlen_case(R.llama3_flash_attn_varlen_func, "llama3[unfused]", llama3=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("ALL OK", flush=True)
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]))

@@ -1,0 +1,45 @@
+"""The RCCL ("nccl" backend) calls of the product path on a one-GPU box: a world-size-1 RCCL group with the
+schedules forced onto their multi-step code path (tests/_rccl_w1_worker.py)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_every_schedule_runs_its_exchange_on_rccl_world_size_1():
+    from conftest import free_port
+
+    env = dict(os.environ)
+    for k in ("RFA_ZIGZAG_EXCHANGE", "RFA_DKV_WIRE", "RFA_LLAMA3_GATHER_MAX_BYTES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_w1_worker.py"), str(free_port())],
+                       capture_output=True, text=True, timeout=900, env=env)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ALL OK" in r.stdout
+
+
+@pytest.mark.parametrize("workload,exchange", [("zigzag", "gather"), ("zigzag", "ring"), ("llama3", None)])
+def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
+    """bench.py's N > 1 branches (RCCL init with device_id, barrier + all_reduce(MAX) on device tensors, the
+    fixed-count spin-up, the loopback `comm` block) on a one-rank RCCL group: one JSON line, with the block"""
+    import json
+
+    env = dict(os.environ)
+    env["RFA_BENCH_FORCE_RCCL"] = "1"
+    env["MASTER_PORT"] = str(__import__("conftest").free_port())
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-breakdown", "--workload", workload]
+    if exchange:
+        cmd += ["--exchange", exchange]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["forced_rccl_world1"] and d["comm"]["backend"] == "nccl" and d["comm"]["compute_only_ms"] > 0
+    assert d["value"] > 0 and d["n_gpus"] == 1
