@@ -449,15 +449,16 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   }
   int qlast = lq;                              // exclusive
   if (lo && kwg0 + kKeys - off + wl < qlast) qlast = kwg0 + kKeys - off + wl;
-  int jt0 = qfirst / kKvQ;
+  const int jt0 = qfirst / kKvQ;
   int jt1 = (qlast + kKvQ - 1) / kKvQ;         // exclusive
   if (jt1 <= jt0) jt1 = jt0;                   // nothing visible: no tiles (the unconditional prologue fetch below
                                                // then reads tile jt0 - 1 >= -1: clamped to 0 there)
-  if (nsplit > 1) {                            // this workgroup's share of the tiles (may be empty: it stores zeros)
-    const int n = jt1 - jt0, first = jt0;
-    jt0 = first + (int)((int64_t)n * qsplit / nsplit);
-    jt1 = first + (int)((int64_t)n * (qsplit + 1) / nsplit);
-  }
+  // This workgroup's share of the tiles jt0 .. jt1-1: every nsplit-th one, counted from the top (jtop, jtop -
+  // nsplit, ...; may be none: it then stores zeros).  Interleaved rather than contiguous ranges so that all
+  // workgroups of a launch — whatever their key block and split — walk down the SAME tiles at about the same
+  // time and the L2 serves a Q/dO tile to all of them (contiguous halves: 2.4x the HBM fetch, measured).
+  const int jtop = jt1 - 1 - qsplit;
+  const int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // time, so the (kv head = XCD) L2 serves a tile to all co-resident key blocks.  (Walking upward from
   // jt0, head after head, spreads them over the whole sequence and every tile is re-fetched from HBM per
   // workgroup: 3.5x the fabric traffic, measured.)
-  int ld_g = 0, ld_j = jt1 > 0 ? jt1 - 1 : 0;         // (head in group, tile) the next load_tile() fetches
+  int ld_g = 0, ld_j = jtop > 0 ? jtop : 0;           // (head in group, tile) the next load_tile() fetches
   auto load_tile = [&]() {
     const int j = RFA_KV_X_LOAD == 2 ? 0 : ld_j;       // (2: measurement, every load hits the same hot tile)
     const T* qbase = qbase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.q_st.head;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
     if (++ld_g >= G) {
       ld_g = 0;
-      --ld_j;
+      ld_j -= nsplit;
     }
     int rows = lq - j * kKvQ;
     rows = rows < kKvQ ? rows : kKvQ;
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #if RFA_KV_PRIO
   if (par == 0) __builtin_amdgcn_s_setprio(2);
 #endif
-  const int ntile = jt1 > jt0 ? (jt1 - jt0) * G : 0;
-  int j = jt1 - 1, cg = 0;
+  const int ntile = ntile_q * G;
+  int j = jtop, cg = 0;
   for (int f = 0; f < ntile; ++f) {
     if (RFA_KV_X_LOAD && f + 1 < ntile) load_tile();
     int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (f + 1 < ntile) write_tile();
     if (++cg >= G) {
       cg = 0;
-      --j;
+      j -= nsplit;
     }
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
 #pragma unroll
