@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RFA_ABI_VERSION 2
+#define RFA_ABI_VERSION 3
 
 typedef enum {
   RFA_OK = 0,
@@ -214,6 +214,22 @@ int rfa_merge(const rfa_merge_args *args, void *stream);
 
 /* dst(io dtype) = (io)src(fp32), n elements, both contiguous */
 int rfa_cast(void *dst, const float *src, int64_t n, int32_t dtype, void *stream);
+
+/* dst[b, row, h, :] = sum over s < nslots of src[s][b, row, h, :]: io dtype in, summed in fp32, io dtype out.
+ * The owner-side sum of the per-rank dK/dV contributions of the all-to-all exchange form — the reference's
+ * `dk = dk_comm_buffer + block_dk` accumulation (zigzag_ring_flash_attn.py:164-187) after the blocks have
+ * travelled in the io dtype instead of fp32 accumulators — written straight into the (possibly strided:
+ * a slice of a packed kv gradient) destination, instead of a sum + cast + copy triple. */
+typedef struct {
+  const void *src;         /* slot 0; slot s starts slot_stride elements further */
+  int64_t slot_stride;
+  int32_t nslots;
+  void *dst;
+  rfa_strides src_st, dst_st;   /* element strides (batch, row, head) inside one slot / of dst; D contiguous */
+  int32_t B, S, H, D;
+  int32_t dtype;
+} rfa_sum_slots_args;
+int rfa_sum_slots(const rfa_sum_slots_args *args, void *stream);
 
 /* LSE re-layout, fp32 (triton_utils.py:39-67,103-137).  The padded tensor is a contiguous
  * (B, H, max_seqlen); the packed tensor has element (h, t) at h*head_stride + t*row_stride, so

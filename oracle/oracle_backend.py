@@ -135,6 +135,10 @@ class OracleBackend:
         out_acc.copy_(new_o)
         lse_acc.copy_(new_l.squeeze(-1).transpose(1, 2))
 
+    def sum_slots(self, src, dst):
+        dst.copy_(src.float().sum(dim=0).to(dst.dtype))
+        return dst
+
     def cast(self, src, dtype):
         return src.to(dtype)
 

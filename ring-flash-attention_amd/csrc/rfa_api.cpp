@@ -303,6 +303,26 @@ int rfa_merge(const rfa_merge_args* a, void* stream) {
   return launch_merge(p, a->dtype, (hipStream_t)stream) ? RFA_ERR_LAUNCH : RFA_OK;
 }
 
+int rfa_sum_slots(const rfa_sum_slots_args* a, void* stream) {
+  if (!a) return RFA_ERR_NULL;
+  int rc = check_common(a->dtype, a->H, a->H, a->D, a->B);
+  if (rc) return rc;
+  if (a->S < 0 || a->nslots < 1) return RFA_ERR_SHAPE;
+  if (a->B == 0 || a->S == 0) return RFA_OK;
+  if (!a->src || !a->dst) return RFA_ERR_NULL;
+  if (!aligned16(a->src) || !aligned16(a->dst) || !stride_ok(a->src_st, 2) || !stride_ok(a->dst_st, 2) ||
+      (a->slot_stride % 8) != 0)
+    return RFA_ERR_ALIGN;
+  ReduceParams r{};
+  r.src = a->src; r.src_st = cv(a->src_st);
+  r.dst = a->dst; r.dst_st = cv(a->dst_st);
+  r.B = a->B; r.Hk = a->H; r.G = a->nslots; r.D = a->D; r.Sk = a->S;
+  r.k_half = RFA_HALF_FULL; r.acc_init = 1;
+  r.g_stride = a->slot_stride;
+  if (launch_reduce(r, a->dtype, (hipStream_t)stream)) return RFA_ERR_LAUNCH;
+  return RFA_OK;
+}
+
 int rfa_cast(void* dst, const float* src, int64_t n, int32_t dtype, void* stream) {
   if (dtype != RFA_BF16 && dtype != RFA_F16) return RFA_ERR_DTYPE;
   if (n < 0) return RFA_ERR_SHAPE;

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   const T* sp = (const T*)p.src + kbatch * p.src_st.batch + arow * p.src_st.row +
-                (int64_t)(hk * p.G) * p.src_st.head + sub * 8;
+                (int64_t)(p.g_stride ? hk : hk * p.G) * p.src_st.head + sub * 8;
+  const int64_t gstep = p.g_stride ? p.g_stride : p.src_st.head;
   for (int gq = 0; gq < p.G; ++gq) {
-    const vec8<T> v = *(const vec8<T>*)(sp + (int64_t)gq * p.src_st.head);
+    const vec8<T> v = *(const vec8<T>*)(sp + (int64_t)gq * gstep);
     // (flash_attn also rounds each per-head dK/dV to the io dtype before its group sum;
     //  the partials are io dtype here too, summed in fp32.)
 #pragma unroll

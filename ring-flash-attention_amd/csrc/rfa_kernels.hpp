@@ -89,6 +89,7 @@ struct ReduceParams {
   const int32_t* cu_k;
   Strides src_st, dst_st, dst_acc_st;
   int B, Hk, G, D, Sk, k_half, acc_init;
+  int64_t g_stride;    // 0: member g of head hk is source head hk*G+g; else: head hk, g_stride elements further per g
 };
 
 struct MergeParams {

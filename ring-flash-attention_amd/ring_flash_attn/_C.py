@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RFA_LIB_PATH: A/B tooling only (tools/ab_variants.py builds tuning variants of the same library)
 LIB_PATH = os.environ.get("RFA_LIB_PATH") or os.path.join(_HERE, "librfa_hip.so")
 
-RFA_ABI_VERSION = 2
+RFA_ABI_VERSION = 3
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
@@ -94,6 +94,16 @@ class MergeArgs(C.Structure):
     ]
 
 
+class SumSlotsArgs(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("slot_stride", C.c_int64), ("nslots", C.c_int32),
+        ("dst", C.c_void_p),
+        ("src_st", Strides), ("dst_st", Strides),
+        ("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32), ("D", C.c_int32),
+        ("dtype", C.c_int32),
+    ]
+
+
 # every symbol include/rfa.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rfa_abi_version": (C.c_int, []),
@@ -104,6 +114,7 @@ SYMBOLS = {
     "rfa_bwd_ds_scratch_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
     "rfa_bwd": (C.c_int, [C.POINTER(BwdArgs), C.c_void_p]),
     "rfa_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
+    "rfa_sum_slots": (C.c_int, [C.POINTER(SumSlotsArgs), C.c_void_p]),
     "rfa_cast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "rfa_lse_flatten": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int64, C.c_int64, C.c_void_p]),

@@ -124,7 +124,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
     return _Fn
 
 
-def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pack_dim, n_packed):
+def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pack_dim, n_packed, packed_travel=False):
     """autograd Function for the packed entry points (`kv` = 2 tensors, `qkv` = 3 tensors stacked on
     `pack_dim`).  Same math as `base_fn`; the only difference is where the gradients land: ONE packed
     buffer whose slices are handed to the schedule as output views (`out_grads`), instead of letting
@@ -145,7 +145,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
             if softmax_scale is None:
                 softmax_scale = q.shape[-1] ** (-0.5)
             _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=window_ok_for(group))
-            q, k, v = _prep_qkv(q, k, v, group)
+            q, k, v = _prep_qkv(q, k, v, group, packed_travel=packed_travel and n_packed == 2)
             tensors_lead = ()
             if n_lead:
                 cu = _as_cu(lead[0], q.device)
@@ -183,7 +183,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
             )
             got = (dq, dk, dv)[3 - n_packed:]
             for view, g in zip(views, got):
-                if g.data_ptr() != view.data_ptr():       # schedule returned its own tensor (W > 1)
+                if g.data_ptr() != view.data_ptr():       # schedule returned its own tensor
                     view.copy_(g)
             grads = (dpacked,) if n_packed == 3 else (dq, dpacked)
             return grads + (None,) * (n_lead + 8)
@@ -195,16 +195,18 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
 def _grad_buffers(out_grads, q, k, v):
     """(dq, dk, dv) output tensors for the single-GPU path: caller-provided views or fresh."""
     og = out_grads or (None, None, None)
-    return (og[0] if og[0] is not None else torch.empty_like(q),
+    return (og[0] if og[0] is not None else (torch.empty_like(q) if q is not None else None),
             og[1] if og[1] is not None else torch.empty_like(k),
             og[2] if og[2] is not None else torch.empty_like(v))
 
 
-def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None):
-    """(B,S,H,D) API: returns (func, kvpacked_func, qkvpacked_func)."""
+def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None, packed_travel=False):
+    """(B,S,H,D) API: returns (func, kvpacked_func, qkvpacked_func).  packed_travel: the schedule exchanges a
+    packed `kv` as one buffer and writes dK/dV straight into the packed gradient (`out_grads`) at any world size."""
     kv_fn = qkv_fn = None
     if forward_impl is not None:
-        kv_fn = make_packed_function(fn.__name__ + "KVPacked", fn, forward_impl, backward_impl, 0, 2, 2)
+        kv_fn = make_packed_function(fn.__name__ + "KVPacked", fn, forward_impl, backward_impl, 0, 2, 2,
+                                     packed_travel=packed_travel)
         qkv_fn = make_packed_function(fn.__name__ + "QKVPacked", fn, forward_impl, backward_impl, 0, 2, 3)
 
     def func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),

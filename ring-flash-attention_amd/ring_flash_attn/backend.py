@@ -235,6 +235,23 @@ class HipBackend:
         a.dtype = self._dtype(block_out)
         _C.check(self.lib.rfa_merge(C.byref(a), _stream(block_out)), "rfa_merge")
 
+    def sum_slots(self, src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+        """dst[...] = sum over dim 0 of src (io dtype, summed in fp32).  src: (W, B, S, H, D) or (W, T, H, D), each slot
+        laid out like dst up to strides; dst may be a strided view (a slice of a packed gradient)."""
+        self._check_dev(src, dst)
+        varlen = dst.dim() == 3
+        a = _C.SumSlotsArgs()
+        a.src, a.dst = _ptr(src), _ptr(dst)
+        a.nslots, a.slot_stride = src.shape[0], src.stride(0)
+        a.src_st, a.dst_st = _st3(src[0], varlen), _st3(dst, varlen)
+        if varlen:
+            a.B, (a.S, a.H, a.D) = 1, dst.shape
+        else:
+            a.B, a.S, a.H, a.D = dst.shape
+        a.dtype = self._dtype(dst)
+        _C.check(self.lib.rfa_sum_slots(C.byref(a), _stream(dst)), "rfa_sum_slots")
+        return dst
+
     def cast(self, src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         """fp32 accumulator -> io dtype (new contiguous tensor)."""
         self._check_dev(src)

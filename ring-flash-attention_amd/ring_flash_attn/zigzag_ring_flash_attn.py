@@ -48,6 +48,7 @@ from . import _C
 from .backend import get_backend
 from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
+from ._common import packed_pair
 
 
 def gather_scratch_bytes(k: torch.Tensor, world: int, wire_fp32: bool) -> int:
@@ -73,8 +74,16 @@ def exchange_mode(k: torch.Tensor, world: int) -> str:
 
 
 def _gather_kv(comm_group, k, v, world):
-    """posts the all-gather of k and v; returns (handle, k_all, v_all) with *_all[(src rank)] views"""
+    """posts the all-gather of k and v; returns (handle, k_all, v_all) with *_all[(src rank)] views.  k and v that are
+    the two halves of one packed kv tensor (kvpacked entry points) travel as that one buffer: one collective of twice
+    the size instead of two, no contiguous copies; the per-rank K / V are then strided views of the gathered buffer."""
     gather = AllGatherComm(comm_group)
+    kv = packed_pair(k, v)
+    if kv is not None:
+        kv_cat = torch.empty((world * kv.shape[0],) + tuple(kv.shape[1:]), dtype=kv.dtype, device=kv.device)
+        gather.all_gather(kv_cat, kv)
+        kv_all = kv_cat.view((world,) + tuple(kv.shape))
+        return gather, kv_all.select(-3, 0), kv_all.select(-3, 1)
     # (world*B, ...) for the collective (the concatenated form every backend accepts), (world, B, ...) to index
     k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
     v_cat = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
@@ -198,9 +207,18 @@ def zigzag_ring_flash_attn_backward(
         # pass.  The owner then sums the W arrivals of its chunk in fp32.
         wire32 = _wire_fp32()
         wdt = torch.float32 if wire32 else q.dtype
-        dk_cat = torch.empty((W * k.shape[0],) + tuple(k.shape[1:]), dtype=wdt, device=q.device)
-        dv_cat = torch.empty((W * v.shape[0],) + tuple(v.shape[1:]), dtype=wdt, device=q.device)
-        dk_all, dv_all = dk_cat.view((W,) + tuple(k.shape)), dv_cat.view((W,) + tuple(v.shape))
+        # k, v that are one packed kv tensor: the contributions are packed the same way and travel as ONE buffer
+        packed = packed_pair(k, v) is not None
+        if packed:
+            pshape = (k.shape[0], k.shape[1], 2) + tuple(k.shape[2:])
+            dkv_cat = torch.empty((W * pshape[0],) + pshape[1:], dtype=wdt, device=q.device)
+            dkv_all = dkv_cat.view((W,) + pshape)
+            dk_all, dv_all = dkv_all.select(-3, 0), dkv_all.select(-3, 1)
+        else:
+            dk_cat = torch.empty((W * k.shape[0],) + tuple(k.shape[1:]), dtype=wdt, device=q.device)
+            dv_cat = torch.empty((W * v.shape[0],) + tuple(v.shape[1:]), dtype=wdt, device=q.device)
+            dk_all, dv_all = dk_cat.view((W,) + tuple(k.shape)), dv_cat.view((W,) + tuple(v.shape))
+        cats = [dkv_cat] if packed else [dk_cat, dv_cat]
 
         def slots(src, rows):
             if wire32:
@@ -215,8 +233,11 @@ def zigzag_ring_flash_attn_backward(
             src = (rank - step) % W
             ks, vs = k_all[src], v_all[src]
             if step <= rank:
-                dk_all[src][:, half:].zero_()
-                dv_all[src][:, half:].zero_()
+                if packed:
+                    dkv_all[src][:, half:].zero_()
+                else:
+                    dk_all[src][:, half:].zero_()
+                    dv_all[src][:, half:].zero_()
                 be.bwd(dout, q, ks[:, :half], vs[:, :half], softmax_lse, delta, softmax_scale=softmax_scale,
                        causal=False, dq_acc=dq, acc_init=False, deterministic=deterministic,
                        phases=_C.BWD_KV_OVERWRITE, **slots(src, slice(0, half)))
@@ -225,22 +246,33 @@ def zigzag_ring_flash_attn_backward(
                        softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:], acc_init=False,
                        deterministic=deterministic, phases=_C.BWD_KV_OVERWRITE, **slots(src, full))
         if wire32:
-            dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
-            dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
-            works = [reduce_scatter_async(dk, dk_cat, group=process_group),
-                     reduce_scatter_async(dv, dv_cat, group=process_group)]
+            sums = [torch.empty((c.shape[0] // W,) + tuple(c.shape[1:]), dtype=torch.float32, device=q.device) for c in cats]
+            works = [reduce_scatter_async(s_, c, group=process_group) for s_, c in zip(sums, cats)]
             dq_out = be.cast(dq, q.dtype)                                  # runs beside the exchange
             for w_ in works:
                 w_.wait()
-            return dq_out, be.cast(dk, q.dtype), be.cast(dv, q.dtype)
-        dk_in, dv_in = torch.empty_like(dk_cat), torch.empty_like(dv_cat)
-        works = [all_to_all_async(dk_in, dk_cat, group=process_group),
-                 all_to_all_async(dv_in, dv_cat, group=process_group)]
+            if packed:
+                dkv = be.cast(sums[0], q.dtype)
+                return dq_out, dkv.select(-3, 0), dkv.select(-3, 1)
+            return dq_out, be.cast(sums[0], q.dtype), be.cast(sums[1], q.dtype)
+        ins = [torch.empty_like(c) for c in cats]
+        works = [all_to_all_async(i_, c, group=process_group) for i_, c in zip(ins, cats)]
         dq_out = be.cast(dq, q.dtype)                                      # runs beside the exchange
         for w_ in works:
             w_.wait()
-        dk = torch.sum(dk_in.view((W,) + tuple(k.shape)), dim=0, dtype=torch.float32).to(q.dtype)
-        dv = torch.sum(dv_in.view((W,) + tuple(v.shape)), dim=0, dtype=torch.float32).to(q.dtype)
+        # owner side: sum the W arrivals of this rank's chunk in fp32, straight into the caller's gradient
+        # buffers when it provided them (the packed kv gradient of the kvpacked entry points)
+        _, dk, dv = _grad_buffers(out_grads, None, k, v)
+        dst = packed_pair(dk, dv) if packed else None
+        if dst is not None:
+            be.sum_slots(ins[0].view((W,) + tuple(dst.shape)).flatten(-3, -2), dst.flatten(-3, -2))
+        elif packed:
+            arr = ins[0].view((W,) + pshape)
+            be.sum_slots(arr.select(-3, 0), dk)
+            be.sum_slots(arr.select(-3, 1), dv)
+        else:
+            be.sum_slots(ins[0].view((W,) + tuple(k.shape)), dk)
+            be.sum_slots(ins[1].view((W,) + tuple(v.shape)), dv)
         return dq_out, dk, dv
 
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
@@ -300,4 +332,4 @@ ZigZagRingFlashAttnFunc = make_autograd_function(
     zigzag_ring_flash_attn_kvpacked_func,
     zigzag_ring_flash_attn_qkvpacked_func,
 ) = make_dense_api(ZigZagRingFlashAttnFunc, "zigzag_ring_flash_attn", zigzag_ring_flash_attn_forward,
-                   zigzag_ring_flash_attn_backward)
+                   zigzag_ring_flash_attn_backward, packed_travel=True)

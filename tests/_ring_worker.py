@@ -113,6 +113,17 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
             _cmp(f"{n}[r{rank}].dv", pick(v.grad.cpu()), ref["dv"], tol["grad"], errs)
             if out.dtype != torch.bfloat16 or q.grad.dtype != torch.bfloat16 or lse.dtype != torch.float32:
                 errs.append(f"{n}: output dtypes {out.dtype} {q.grad.dtype} {lse.dtype}")
+            if kind == "zigzag":
+                # the kvpacked entry point: K/V travel as ONE packed buffer, dK/dV land in the packed gradient
+                q2 = q.detach().clone().requires_grad_(True)
+                kv = torch.stack([k.detach(), v.detach()], dim=2).requires_grad_(True)
+                out2, lse2, _ = R.zigzag_ring_flash_attn_kvpacked_func(q2, kv, causal=True, **kw)
+                out2.backward(do)
+                _cmp(f"{n}[r{rank}].kvpacked.out", pick(out2.detach().cpu()), ref["out"], tol["out"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.lse", lse2.detach().cpu(), ref["lse"], tol["lse"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dq", pick(q2.grad.cpu()), ref["dq"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dk", pick(kv.grad[:, :, 0].cpu()), ref["dk"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dv", pick(kv.grad[:, :, 1].cpu()), ref["dv"], tol["grad"], errs)
         ret[rank] = errs
         dist.barrier()
         dist.destroy_process_group()

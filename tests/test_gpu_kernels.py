@@ -202,6 +202,31 @@ def test_merge_kernel_is_reference_update_out_and_lse():
         update_out_and_lse(None, None, b0.to(dev), l0.to(dev), slice_=(slice(None),))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sum_slots_kernel_strided_destination(dtype):
+    """rfa_sum_slots: W io-dtype contributions summed in fp32 into a slice of a packed gradient (dense) and into a
+    packed-sequence tensor (T,H,D); bit-exact against the same fp32 sum rounded once."""
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    W, B, S, Hk, D = 5, 2, 300, 3, 128
+    slots = torch.randn(W, B, S, 2, Hk, D, generator=g).to(dtype).to(dev)
+    packed = torch.full((B, S, 2, Hk, D), 7.0, dtype=dtype, device=dev)
+    be.sum_slots(slots[:, :, :, 1], packed[:, :, 1])                       # strided source slices, strided destination
+    ref = slots[:, :, :, 1].float().sum(0).to(dtype)
+    assert torch.equal(packed[:, :, 1], ref) and bool((packed[:, :, 0] == 7.0).all())
+    whole = torch.empty_like(packed)
+    be.sum_slots(slots.flatten(-3, -2), whole.flatten(-3, -2))             # the packed tensor in one launch
+    assert torch.equal(whole, slots.float().sum(0).to(dtype))
+    tv = torch.randn(W, 777, 4, 64, generator=g).to(dtype).to(dev)         # (T,H,D), head dim 64
+    dst = torch.empty(777, 4, 64, dtype=dtype, device=dev)
+    be.sum_slots(tv, dst)
+    assert torch.equal(dst, tv.float().sum(0).to(dtype))
+
+
 def test_lse_flatten_unflatten_bit_exact():
     """reference test/test_triton_kernels.py: re-layout must be bit-identical (cu [0,15,156,529])."""
     from ring_flash_attn.utils import flatten_varlen_lse, unflatten_varlen_lse
