@@ -79,18 +79,26 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   const int b = idx / p.nqblk;
   const int h = hk * G + gq;
 
-  const int lq = p.Sq, lk = p.Sk;                       // dense only (rfa_api.cpp checks)
+  // dense, or packed sequences (cu_seqlens; whole sequences only: rfa_api.cpp checks)
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
   const int qwg0 = qblk * kDsRows;
   if (qwg0 >= lq) return;
   const int off = lk - lq;
   const int qw0 = qwg0 + wave * 32;
   const int qrow = qw0 + l31;
 
-  const T* kbase = (const T*)p.k + (int64_t)b * p.k_st.batch + (int64_t)hk * p.k_st.head;
-  const int nQt = (lq + 31) >> 5, nKb = (lk + 31) >> 5;
-  // this wave's run of dS blocks: (b, h, qt = qw0 / 32, kb = 0 .. nKb-1), contiguous
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  // scratch layout: (b, h, qt, kb) with the extents of the LONGEST sequence (p.Sq, p.Sk = max_seqlen for packed
+  // input; = the sequence length when dense), of which this sequence uses the first ceil(lk / 32) key blocks of
+  // its first ceil(lq / 32) rows of blocks
+  const int nQt = (p.Sq + 31) >> 5, nKb = (p.Sk + 31) >> 5;
+  // this wave's run of dS blocks: (b, h, qt = qw0 / 32, kb = 0 .. ceil(lk/32)-1), contiguous
   const char* srun = (const char*)p.ds + ((((int64_t)b * p.H + h) * nQt + (qw0 >> 5)) * nKb) * (int64_t)kDsBlockBytes;
-  const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? nKb * kDsBlockBytes : 0);
+  const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? ((lk + 31) >> 5) * kDsBlockBytes : 0);
 
   const int qend = (qwg0 + kDsRows < lq) ? qwg0 + kDsRows : lq;
   int kmax = lk;                                        // (windowed calls are not eligible for the spill path)
@@ -206,10 +214,10 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
 
   if (qrow >= lq) return;
   if (p.dq_acc == nullptr) {
-    T* ob = (T*)p.dq + (int64_t)b * p.dq_st.batch + (int64_t)qrow * p.dq_st.row + (int64_t)h * p.dq_st.head;
+    T* ob = (T*)p.dq + qbatch * p.dq_st.batch + (qs.row0 + qrow) * p.dq_st.row + (int64_t)h * p.dq_st.head;
     store_rows16<T, true>(ob, dq, p.scale, g, p.D, true);
   } else {
-    float* ab = p.dq_acc + (int64_t)b * p.dq_acc_st.batch + (int64_t)qrow * p.dq_acc_st.row +
+    float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + (qs.row0 + qrow) * p.dq_acc_st.row +
                 (int64_t)h * p.dq_acc_st.head;
 #pragma unroll
     for (int dblk = 0; dblk < 4; ++dblk)

@@ -186,7 +186,7 @@ class HipBackend:
         a.dtype = self._dtype(q)
         a.phases = phases
         # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
-        # recomputing S and dP, when the call is eligible (dense, D == 128) and the scratch stays below
+        # recomputing S and dP, when the call is eligible (D == 128, whole sequences, dense or packed) and the scratch stays below
         # RFA_DS_SPILL_MAX_BYTES; RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
         # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
         reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
@@ -294,7 +294,7 @@ def _spill_enabled() -> bool:
 
 def _spill_limit() -> int:
     import os
-    return int(os.environ.get("RFA_DS_SPILL_MAX_BYTES", str(8 << 30)))
+    return int(os.environ.get("RFA_DS_SPILL_MAX_BYTES", str(16 << 30)))
 
 
 _backend = None

@@ -100,15 +100,17 @@ def test_dense_qkvpacked_reference_fixture(single_rank_group, monkeypatch, api, 
     _grads_ok(api, (x.grad[:, :, 0], x.grad[:, :, 1], x.grad[:, :, 2]), (dq, dk, dv))
 
 
+@pytest.mark.parametrize("spill", ["1", "0"])
 @pytest.mark.parametrize("nsplit", [None, "2"])
 @pytest.mark.parametrize("api,cu", [("zigzag", [0, 128, 1248, 4240]), ("ring", [0, 120, 1248, 4232])])
-def test_varlen_reference_fixture(single_rank_group, monkeypatch, api, cu, nsplit):
+def test_varlen_reference_fixture(single_rank_group, monkeypatch, api, cu, nsplit, spill):
     """reference test/test_{zigzag_,}ring_flash_attn_varlen_func.py at world_size 1 (H=5, D=128); nsplit: the
     256-key dK/dV form forced onto this small shape (csrc/rfa_api.cpp bwd_dkdv_plan)."""
     import ring_flash_attn as R
 
     if nsplit:
         monkeypatch.setenv("RFA_DKDV_NSPLIT", nsplit)
+    monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)       # 5-GEMM (dS spill, packed layout) / 7-GEMM backward
 
     dev = _dev()
     g = torch.Generator().manual_seed(43)
@@ -406,6 +408,44 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
             _grads_ok(f"nsplit={nsplit} spill={spill} {mode}", got, (rdq, rdk, rdv))
             for n, a_, b_ in zip(("dk", "dv"), got[1:], narrow[mode][1:]):      # same math, other summation order
                 _check(f"nsplit={nsplit} spill={spill} {mode}.{n} vs 128-key form", a_, b_.float(), 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_ds_spill_packed_sequences_with_longer_keys(monkeypatch, causal):
+    """dS-spill backward on packed sequences whose K/V are longer than Q (the llama3 shape: local queries against
+    gathered keys, bottom-right aligned), with empty and 1-token sequences, against the oracle and against the
+    recompute backward (dK/dV bit for bit)."""
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    cu_q = torch.tensor([0, 100, 100, 101, 700, 1000], dtype=torch.int32)
+    cu_k = torch.tensor([0, 300, 300, 333, 1500, 1800], dtype=torch.int32)
+    Tq, Tk, H, Hk = 1000, 1800, 4, 2
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(Tq, H, 128, generator=g).to(BF)
+    k = torch.randn(Tk, Hk, 128, generator=g).to(BF)
+    v = torch.randn(Tk, Hk, 128, generator=g).to(BF)
+    do = torch.randn(Tq, H, 128, generator=g).to(BF)
+    ro, rl, rdq, rdk, rdv = _oracle_varlen(q, k, v, do, cu_q, cu_k, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    kw = dict(softmax_scale=128 ** -0.5, causal=causal, cu_seqlens_q=cu_q.to(dev), cu_seqlens_k=cu_k.to(dev),
+              max_seqlen_q=599, max_seqlen_k=1167)
+    out = torch.empty_like(qd)
+    lse = torch.empty((H, Tq), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, out=out, lse=lse, **kw)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta, cu_seqlens_q=kw["cu_seqlens_q"], max_seqlen_q=599)
+    res = {}
+    for spill in ("1", "0"):
+        monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq=dq, dk=dk, dv=dv, **kw)
+        _grads_ok(f"packed spill={spill}", (dq, dk, dv), (rdq, rdk, rdv))
+        res[spill] = (dq, dk, dv)
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+    _check("dq spill vs recompute", res["1"][0], res["0"][0].float(), 1e-2, 2e-2)
 
 
 def test_torch_compile_fullgraph_on_gpu(single_rank_group):
