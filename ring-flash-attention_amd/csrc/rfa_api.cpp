@@ -143,7 +143,14 @@ static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if (!env_wide || a->D != kHeadDim || win) return pl;
   const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
-  const int64_t wgs = (int64_t)a->B * a->Hk * ((sk + 255) / 256);
+  // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) key blocks per K/V head, of which
+  // only about total_k / 256 (+ one tail per sequence) are not past the end of their sequence
+  int64_t kblocks = (int64_t)a->B * ((sk + 255) / 256);
+  if (a->cu_seqlens_k != nullptr && a->total_k > 0) {
+    const int64_t eff = (a->total_k + 255) / 256 + a->B;
+    kblocks = eff < kblocks ? eff : kblocks;
+  }
+  const int64_t wgs = kblocks * a->Hk;
   int ns = 1;
   while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 512) ++ns;
   if (env_nsplit > 0) ns = env_nsplit > 8 ? 8 : env_nsplit;

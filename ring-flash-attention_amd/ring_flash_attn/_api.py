@@ -251,8 +251,13 @@ def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None, packed_tra
     return _compilable(func, lower), _compilable(kvpacked_func, lower_kv), _compilable(qkvpacked_func, lower_qkv)
 
 
-def make_varlen_api(fn, prefix):
-    """(T,H,D) + (cu_seqlens, max_seqlen) API."""
+def make_varlen_api(fn, prefix, forward_impl=None, backward_impl=None):
+    """(T,H,D) + (cu_seqlens, max_seqlen) API.  With the schedule's forward / backward the packed entry points get
+    their own autograd Function (gradients land in ONE packed buffer, see make_packed_function)."""
+    kv_fn = qkv_fn = None
+    if forward_impl is not None:
+        kv_fn = make_packed_function(fn.__name__ + "KVPacked", fn, forward_impl, backward_impl, 2, 1, 2)
+        qkv_fn = make_packed_function(fn.__name__ + "QKVPacked", fn, forward_impl, backward_impl, 2, 1, 3)
 
     def func(q, k, v, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
              window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False,
@@ -263,12 +268,18 @@ def make_varlen_api(fn, prefix):
     def kvpacked_func(q, kv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                       window_size=(-1, -1), alibi_slopes=None, deterministic=False,
                       return_attn_probs=False, group=None):
+        if kv_fn is not None:
+            return kv_fn.apply(q, kv, cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal, window_size,
+                               alibi_slopes, deterministic, return_attn_probs, group)
         return fn.apply(q, kv[:, 0], kv[:, 1], cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal,
                         window_size, alibi_slopes, deterministic, return_attn_probs, group)
 
     def qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
                        window_size=(-1, -1), alibi_slopes=None, deterministic=False,
                        return_attn_probs=False, group=None):
+        if qkv_fn is not None:
+            return qkv_fn.apply(qkv, cu_seqlens, max_seqlen, dropout_p, softmax_scale, causal, window_size,
+                                alibi_slopes, deterministic, return_attn_probs, group)
         return fn.apply(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens, max_seqlen, dropout_p, softmax_scale,
                         causal, window_size, alibi_slopes, deterministic, return_attn_probs, group)
 

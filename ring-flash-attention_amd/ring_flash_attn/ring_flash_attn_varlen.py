@@ -12,7 +12,7 @@ import torch
 from . import _C
 from .backend import get_backend
 from .utils import RingComm, single_rank
-from ._api import make_autograd_function, make_varlen_api
+from ._api import make_autograd_function, make_varlen_api, _grad_buffers
 
 
 def ring_flash_attn_varlen_forward(
@@ -74,6 +74,7 @@ def ring_flash_attn_varlen_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    out_grads=None,
 ):
     be = get_backend()
     kv_comm = RingComm(process_group)
@@ -89,7 +90,7 @@ def ring_flash_attn_varlen_backward(
     be.bwd_preprocess(dout, out, delta, cu_seqlens_q=cu_seqlens, max_seqlen_q=max_seqlen)
 
     if single_rank(kv_comm.world_size):
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=causal,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, **vl)
         return dq, dk, dv
@@ -137,4 +138,4 @@ RingFlashAttnVarlenFunc = make_autograd_function(
     ring_flash_attn_varlen_func,
     ring_flash_attn_varlen_kvpacked_func,
     ring_flash_attn_varlen_qkvpacked_func,
-) = make_varlen_api(RingFlashAttnVarlenFunc, "ring_flash_attn_varlen")
+) = make_varlen_api(RingFlashAttnVarlenFunc, "ring_flash_attn_varlen", ring_flash_attn_varlen_forward, ring_flash_attn_varlen_backward)

@@ -18,7 +18,7 @@ import torch
 from . import _C
 from .backend import get_backend, HALF_FRONT, HALF_BACK
 from .utils import RingComm, single_rank
-from ._api import make_autograd_function, make_varlen_api
+from ._api import make_autograd_function, make_varlen_api, _grad_buffers
 
 
 def get_half_index(cu_seqlens, *, front: bool):
@@ -123,6 +123,7 @@ def zigzag_ring_flash_attn_varlen_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    out_grads=None,
 ):
     assert causal == True, "zigzag ring is meaningless for causal=False"
     be = get_backend()
@@ -139,7 +140,7 @@ def zigzag_ring_flash_attn_varlen_backward(
     be.bwd_preprocess(dout, out, delta, cu_seqlens_q=cu_seqlens, max_seqlen_q=max_seqlen)
 
     if single_rank(kv_comm.world_size):
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
                dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, **vl)
         return dq, dk, dv
@@ -192,4 +193,4 @@ ZigZagRingFlashAttnVarlenFunc = make_autograd_function(
     zigzag_ring_flash_attn_varlen_func,
     zigzag_ring_flash_attn_varlen_kvpacked_func,
     zigzag_ring_flash_attn_varlen_qkvpacked_func,
-) = make_varlen_api(ZigZagRingFlashAttnVarlenFunc, "zigzag_ring_flash_attn_varlen")
+) = make_varlen_api(ZigZagRingFlashAttnVarlenFunc, "zigzag_ring_flash_attn_varlen", zigzag_ring_flash_attn_varlen_forward, zigzag_ring_flash_attn_varlen_backward)

@@ -113,6 +113,18 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
             _cmp(f"{n}[r{rank}].dv", pick(v.grad.cpu()), ref["dv"], tol["grad"], errs)
             if out.dtype != torch.bfloat16 or q.grad.dtype != torch.bfloat16 or lse.dtype != torch.float32:
                 errs.append(f"{n}: output dtypes {out.dtype} {q.grad.dtype} {lse.dtype}")
+            if kind in ("zigzag_varlen", "ring_varlen"):
+                # packed entry point of the varlen schedules (own autograd Function: packed gradient buffer)
+                fnp = R.zigzag_ring_flash_attn_varlen_kvpacked_func if kind == "zigzag_varlen" else R.ring_flash_attn_varlen_kvpacked_func
+                q2 = q.detach().clone().requires_grad_(True)
+                kv = torch.stack([k.detach(), v.detach()], dim=1).requires_grad_(True)
+                out2, lse2, _ = fnp(q2, kv, extra["cu_local"].to(dev), extra["max_local"],
+                                    causal=True if kind == "zigzag_varlen" else c["causal"], **kw)
+                out2.backward(do)
+                _cmp(f"{n}[r{rank}].kvpacked.out", pick(out2.detach().cpu()), ref["out"], tol["out"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dq", pick(q2.grad.cpu()), ref["dq"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dk", pick(kv.grad[:, 0].cpu()), ref["dk"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dv", pick(kv.grad[:, 1].cpu()), ref["dv"], tol["grad"], errs)
             if kind == "zigzag":
                 # the kvpacked entry point: K/V travel as ONE packed buffer, dK/dV land in the packed gradient
                 q2 = q.detach().clone().requires_grad_(True)
