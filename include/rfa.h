@@ -164,7 +164,7 @@ typedef struct {
    * kernel stores dS = P*(dP - delta) of every (32 query x 32 key) block it visits and dQ is computed by a
    * streaming GEMM over those blocks instead of recomputing S and dP (csrc/rfa_dqs.hip).  The contents are
    * only meaningful between the two kernels of one call (or between a RFA_BWD_SKIP_DQ call and the matching
-   * RFA_BWD_SKIP_DKDV call).  Eligible: D == 128, no half selection, no bounded left window — dense or packed
+   * RFA_BWD_SKIP_DKDV call).  Eligible: D == 128, no bounded left window — dense or packed
    * (cu_seqlens: the scratch is then laid out with the extents of the longest sequence, Sq / Sk = max_seqlen). */
   void *ds_scratch;
   int32_t window, window_left, window_right; /* as in rfa_fwd_args (a bounded window_left is not eligible for ds_scratch) */
@@ -209,7 +209,7 @@ int rfa_fwd(const rfa_fwd_args *args, void *stream);
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
 /* bytes of ds_scratch the call would use (B*H*ceil(Sq/32)*ceil(Sk/32)*2048; packed input: B sequences, Sq / Sk =
- * max_seqlen_q / _k), or 0 if it is not eligible */
+ * max_seqlen_q / _k; with q_half / k_half: ceil(S/2) instead of S), or 0 if it is not eligible */
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args *args);
 int rfa_bwd(const rfa_bwd_args *args, void *stream);
 int rfa_merge(const rfa_merge_args *args, void *stream);

@@ -167,13 +167,13 @@ static bool bwd_needs_ws(const rfa_bwd_args* a) {
 
 static bool bwd_spill_eligible(const rfa_bwd_args* a) {
   return (a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && a->D == kHeadDim &&
-         a->q_half == RFA_HALF_FULL && a->k_half == RFA_HALF_FULL && a->B > 0 && a->Sq > 0 && a->Sk > 0 &&
+         a->B > 0 && a->Sq > 0 && a->Sk > 0 &&
          !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
 }
 
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_spill_eligible(a)) return 0;
-  return (int64_t)a->B * a->H * ((a->Sq + 31) / 32) * ((a->Sk + 31) / 32) * kDsBlockBytes;
+  return (int64_t)a->B * a->H * ds_blocks(a->Sq, a->q_half) * ds_blocks(a->Sk, a->k_half) * kDsBlockBytes;
 }
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {

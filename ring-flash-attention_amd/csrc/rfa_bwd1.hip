@@ -236,8 +236,8 @@ __global__ __launch_bounds__(kW1Threads, 1) void dkdv1_kernel(const BwdParams p)
   pin_vgpr(aq); pin_vgpr(tq[0]); pin_vgpr(tq[1]); pin_vgpr(sa); pin_vgpr(ws);
 
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
-  const int ds_nkb = (p.Sk + 31) >> 5;          // extents of the longest sequence (= lk, lq when dense): rfa_dqs.hip
-  const int64_t ds_head_bytes = (int64_t)((p.Sq + 31) >> 5) * ds_nkb * kDsBlockBytes;
+  const int ds_nkb = ds_blocks(p.Sk, p.k_half);  // extents of the longest (half) sequence (= lk, lq when dense): rfa_dqs.hip
+  const int64_t ds_head_bytes = (int64_t)ds_blocks(p.Sq, p.q_half) * ds_nkb * kDsBlockBytes;
   const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * 4 + wave);
 

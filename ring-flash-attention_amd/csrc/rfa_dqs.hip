@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   const int b = idx / p.nqblk;
   const int h = hk * G + gq;
 
-  // dense, or packed sequences (cu_seqlens; whole sequences only: rfa_api.cpp checks)
+  // dense, or packed sequences (cu_seqlens), whole or the front / back half of every sequence
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
   const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
   const int lq = qs.len, lk = ks.len;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   // scratch layout: (b, h, qt, kb) with the extents of the LONGEST sequence (p.Sq, p.Sk = max_seqlen for packed
   // input; = the sequence length when dense), of which this sequence uses the first ceil(lk / 32) key blocks of
   // its first ceil(lq / 32) rows of blocks
-  const int nQt = (p.Sq + 31) >> 5, nKb = (p.Sk + 31) >> 5;
+  const int nQt = ds_blocks(p.Sq, p.q_half), nKb = ds_blocks(p.Sk, p.k_half);
   // this wave's run of dS blocks: (b, h, qt = qw0 / 32, kb = 0 .. ceil(lk/32)-1), contiguous
   const char* srun = (const char*)p.ds + ((((int64_t)b * p.H + h) * nQt + (qw0 >> 5)) * nKb) * (int64_t)kDsBlockBytes;
   const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? ((lk + 31) >> 5) * kDsBlockBytes : 0);

@@ -113,7 +113,9 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dkdv1(const BwdParams& p, int dtype, hipStream_t stream);
 // dQ = scale * dS K from the dS blocks a preceding launch_bwd_dkdv (with p.ds set) stored; dense, D == 128
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream);
-constexpr int kDsBlockBytes = 2048;   // one (32 query x 32 key) block of dS in the io dtype
+constexpr int kDsBlockBytes = 2048;
+// rows / columns of 32 x 32 dS blocks the spill scratch reserves per (sequence, head): the longest (half) sequence
+__host__ __device__ inline int ds_blocks(int S, int half) { return ((half ? (S + 1) / 2 : S) + 31) >> 5; }   // one (32 query x 32 key) block of dS in the io dtype
 int bwd_dq_rows_per_block();
 int bwd_dkdv_keys_per_block(bool wide);
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);
