@@ -9,12 +9,18 @@
 // Deterministic by construction: no atomics.  The work is split by OUTPUT ownership:
 //   * dq_kernel    : a workgroup owns 256 query rows, streams K/V tiles through LDS
 //                    (S,dP recomputed per tile), accumulates dQ in registers, and either
-//                    stores it or adds it into a caller fp32 accumulator (ring steps).
-//   * dkdv_kernel  : a workgroup owns 128 keys of ONE K/V head (its V rows resident in LDS, each
-//                    wave's K rows in registers), streams the Q/dO tiles of ALL query heads of that
-//                    K/V group through LDS and accumulates dK,dV of the whole group in registers
-//                    (8 waves = 4 key blocks x 2 sub-tile parities) — no per-head partials and no
-//                    group-reduction pass.  rfa_aux.hip: reduce_kernel only serves accumulate /
+//                    stores it or adds it into a caller fp32 accumulator (ring steps).  The 7-GEMM
+//                    form: head dim != 128, bounded left windows, spill switched off / over its
+//                    memory limit.  Otherwise dQ comes from rfa_dqs.hip (dq_ds_kernel), which streams
+//                    the dS blocks the dK/dV kernel spilled (kSpill) instead of recomputing S and dP.
+//   * dkdv_kernel  : a workgroup owns 128 (256: kWide) keys of ONE K/V head (its V rows resident in
+//                    LDS, each wave's K rows in registers), streams the Q/dO tiles of ALL query heads
+//                    of that K/V group through LDS and accumulates dK,dV of the whole group in
+//                    registers — no per-head partials and no group-reduction pass.  8 waves = 4 key
+//                    blocks x 2 sub-tile parities, or (kWide, the headline launch) 8 key blocks whose
+//                    waves run both sub-tiles; the kWide form may share a key block's query range
+//                    between workgroups (rfa_api.cpp: bwd_dkdv_plan), whose io-dtype partials
+//                    rfa_aux.hip's reduce_kernel sums.  reduce_kernel also serves accumulate /
 //                    two-phase calls (workspace partials -> fp32 accumulators).
 // Lane ownership mirrors the forward kernel (see rfa_common.hpp): after the first GEMM a
 // lane owns one query row (dQ kernel) or one key (dK/dV kernel), and the probabilities go

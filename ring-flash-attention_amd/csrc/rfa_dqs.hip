@@ -12,7 +12,9 @@
 // to the io dtype that the dK GEMM uses.
 //
 // Scratch layout (written by dkdv_kernel<kSpill>, read here): blocks of 2048 bytes indexed
-//        [batch][q head][qt = query row / 32][kb = key / 32]
+//        [batch or packed sequence][q head][qt = query row / 32][kb = key / 32]
+// (row / key counted inside the sequence — or inside its selected half; the qt / kb extents are those of the
+//  longest (half) sequence of the call, ds_blocks() in rfa_kernels.hpp, so packed input needs no offset table)
 // holding dS[32 q][32 keys] as 128 slots of 16 bytes; slot p = 16·(key>>2) + 8·i + 4·g + (key&3) contains
 // (for key = 0..31 of the block, i = 0/1, g = 0/1) the 8 values q = 16i + 4g + {0..3}, 16i + 8 + 4g + {0..3}
 // of that key.  This is the image that makes the transposed LDS read below conflict-free after a

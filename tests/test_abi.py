@@ -185,3 +185,57 @@ def test_flash_attn_shim_surface(built):
         F._flash_attn_forward(q, q, q, 0.1, 0.125, True)
     with pytest.raises(NotImplementedError):
         F._flash_attn_forward(q, q, q, 0.0, 0.125, True, softcap=30.0)
+
+
+def test_backward_plan_is_a_function_of_the_shapes(built, monkeypatch):
+    """rfa_bwd_workspace_bytes / rfa_bwd_ds_scratch_bytes (host code): which dK/dV kernel form a call runs and
+    how much scratch it asks for — the numbers DESIGN.md quotes for the headline, and the rule that a
+    BWD_COMPUTE / BWD_REDUCE pair and the sizing call agree because only shapes enter."""
+    from ring_flash_attn import _C
+
+    lib = _C.load()
+    for k in ("RFA_DKDV_WIDE", "RFA_DKDV_NSPLIT"):
+        monkeypatch.delenv(k, raising=False)
+
+    def args(B, Sq, Sk, H, Hk, D=128, varlen_total=None, acc=False, phases=0, window=None, halves=(0, 0)):
+        a = _C.BwdArgs()
+        a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype = B, Sq, Sk, H, Hk, D, 0
+        a.total_k = varlen_total if varlen_total is not None else B * Sk
+        if varlen_total is not None:
+            a.cu_seqlens_q = a.cu_seqlens_k = 1                  # non-null: host code never dereferences them
+        if acc:
+            a.dk_acc = a.dv_acc = 1
+        a.phases = phases
+        a.q_half, a.k_half = halves
+        if window:
+            a.window, a.window_left, a.window_right = 1, window[0], window[1]
+        return a
+
+    unit = lambda rows, Hk, D=128: 2 * rows * Hk * D * 2        # one (dK, dV) partial set in the io dtype
+    ws = lambda a: lib.rfa_bwd_workspace_bytes(C.byref(a))
+    ds = lambda a: lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
+    # headline (GQA 32:8, S = 8192): 256-key form, two workgroups per key block -> two partial sets
+    assert ws(args(1, 8192, 8192, 32, 8)) == 2 * unit(8192, 8)
+    assert ds(args(1, 8192, 8192, 32, 8)) == 32 * 256 * 256 * 2048
+    # MHA: 1024 workgroups already, no split -> plain outputs need no workspace; accumulate / phased calls do
+    assert ws(args(1, 8192, 8192, 32, 32)) == 0
+    assert ws(args(1, 8192, 8192, 32, 32, acc=True)) == unit(8192, 32)
+    assert ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_COMPUTE)) == ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_REDUCE))
+    # ring "front" step of world size 8 (all queries x 4096 keys): four workgroups per key block
+    assert ws(args(1, 8192, 4096, 32, 8)) == 4 * unit(4096, 8)
+    # small launches, head dim 64 and windows keep the 128-key form (no split, no workspace)
+    assert ws(args(1, 1024, 1024, 4, 2)) == 0
+    assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert ws(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0 and ds(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0
+    # packed sequences: the form is chosen from the packed row count, the scratch from the longest sequence;
+    # half-sequence steps reserve half the blocks per axis
+    assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit(8192, 8)
+    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 3 * 32 * 231 * 231 * 2048
+    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 3 * 32 * 116 * 116 * 2048
+    # the overrides
+    monkeypatch.setenv("RFA_DKDV_WIDE", "0")
+    assert ws(args(1, 8192, 8192, 32, 8)) == 0
+    monkeypatch.setenv("RFA_DKDV_WIDE", "1")
+    monkeypatch.setenv("RFA_DKDV_NSPLIT", "3")
+    assert ws(args(1, 1024, 1024, 4, 2)) == 3 * unit(1024, 2)
+
