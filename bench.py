@@ -201,7 +201,8 @@ def comm_bytes_per_iter(mode, wire_fp32, world, hk):
     if mode == "ring":                                   # (W-1) M fwd, (W-1) M + W 2M (fp32 dK/dV) bwd
         return (world - 1) * m + (world - 1) * m + world * 2 * m
     contrib = (2 * m) if wire_fp32 else m                # dK + dV contribution for one chunk
-    return (world - 1) * m + (world - 1) * m + (world - 1) * contrib
+    # one all-gather (the backward reuses the K/V the forward gathered) + one all-to-all / reduce-scatter
+    return (world - 1) * m + (world - 1) * contrib
 
 
 def main():

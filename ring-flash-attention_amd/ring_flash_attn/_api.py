@@ -13,6 +13,7 @@ inputs are the caller's LOCAL shard.
 import torch
 
 from ._common import _prep_qkv, _as_cu
+from .utils import backward_expected
 
 
 def _opaque(fn):
@@ -97,10 +98,11 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 cu = _as_cu(lead[0], q.device)
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
-            out, softmax_lse = forward_impl(
-                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
-                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
-            )
+            with backward_expected(any(ctx.needs_input_grad[:3])):
+                out, softmax_lse = forward_impl(
+                    group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                    window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+                )
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale
@@ -151,10 +153,11 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 cu = _as_cu(lead[0], q.device)
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
-            out, softmax_lse = forward_impl(
-                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
-                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
-            )
+            with backward_expected(any(ctx.needs_input_grad[:3])):
+                out, softmax_lse = forward_impl(
+                    group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                    window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+                )
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale

@@ -116,6 +116,28 @@ def single_rank(world_size: int) -> bool:
     return world_size == 1 and os.environ.get("RFA_TEST_FORCE_STEPS", "0") != "1"
 
 
+# Set by the autograd Functions around a schedule's forward: will a backward follow (an input needs a gradient)?
+# The zigzag gather form keeps its gathered K/V for that backward only then.
+_BACKWARD_EXPECTED = False
+
+
+class backward_expected:
+    def __init__(self, flag: bool):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global _BACKWARD_EXPECTED
+        self.prev, _BACKWARD_EXPECTED = _BACKWARD_EXPECTED, self.flag
+
+    def __exit__(self, *exc):
+        global _BACKWARD_EXPECTED
+        _BACKWARD_EXPECTED = self.prev
+
+
+def is_backward_expected() -> bool:
+    return _BACKWARD_EXPECTED
+
+
 def group_rank_world(process_group):
     """(rank, world_size) of the group — the one place the schedules ask for it"""
     if _LOOPBACK is not None:

@@ -46,7 +46,8 @@ import torch
 
 from . import _C
 from .backend import get_backend
-from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
+from .utils import (AllGatherComm, RingComm, all_to_all_async, is_backward_expected, reduce_scatter_async,
+                    single_rank)
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 from ._common import packed_pair
 
@@ -71,6 +72,43 @@ def exchange_mode(k: torch.Tensor, world: int) -> str:
         limit = int(os.environ.get("RFA_GATHER_MAX_BYTES", str(4 << 30)))
         mode = "gather" if gather_scratch_bytes(k, world, _wire_fp32()) <= limit else "ring"
     return mode
+
+
+# ---------------------------------------------------------------------------------------------
+# The K/V gathered by a forward are kept for its backward (W x (K, V) io dtype per pending backward: 0.27 GB at
+# W = 8, Hk = 8, S = 8192/rank) instead of being gathered a second time.  With the K/V already present the backward
+# can run its REMOTE steps first and the local causal block last, so that the one all-to-all of the dK/dV
+# contributions is posted before the local block and runs beside it — no exchange is left on the critical path
+# of the backward.  Entries hold a reference to the k / v they were gathered from (so their addresses cannot be
+# recycled while the entry lives) and are matched on address, shape, dtype and tensor version; a miss (evicted,
+# RFA_ZIGZAG_KV_CACHE=0, checkpointing that dropped it) gathers again and keeps the local-block-first order.
+_KV_CACHE = {}          # insertion ordered: oldest first
+
+
+def _kv_cache_limit() -> int:
+    if os.environ.get("RFA_ZIGZAG_KV_CACHE", "1") == "0":
+        return 0
+    return int(os.environ.get("RFA_ZIGZAG_KV_CACHE_BYTES", str(2 << 30)))
+
+
+def _kv_key(group, k, v, world, rank):
+    return (id(group), k.data_ptr(), v.data_ptr(), tuple(k.shape), tuple(k.stride()), k.dtype, k._version,
+            v._version, world, rank)
+
+
+def _kv_cache_put(group, k, v, world, rank, k_all, v_all):
+    limit = _kv_cache_limit()
+    nbytes = 2 * world * k.numel() * k.element_size()
+    if nbytes > limit:
+        return
+    _KV_CACHE[_kv_key(group, k, v, world, rank)] = (k, v, k_all, v_all, nbytes)
+    while sum(e[4] for e in _KV_CACHE.values()) > limit:
+        _KV_CACHE.pop(next(iter(_KV_CACHE)))
+
+
+def _kv_cache_take(group, k, v, world, rank):
+    e = _KV_CACHE.pop(_kv_key(group, k, v, world, rank), None)
+    return None if e is None else (e[2], e[3])
 
 
 def _gather_kv(comm_group, k, v, world):
@@ -124,6 +162,8 @@ def zigzag_ring_flash_attn_forward(
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
         gather.wait()
+        if is_backward_expected():
+            _kv_cache_put(process_group, k, v, comm.world_size, comm.rank, k_all, v_all)
         for step in range(1, comm.world_size):
             src = (comm.rank - step) % comm.world_size
             ks, vs = k_all[src], v_all[src]
@@ -199,13 +239,20 @@ def zigzag_ring_flash_attn_backward(
 
     if exchange_mode(k, kv_comm.world_size) == "gather":
         W, rank = kv_comm.world_size, kv_comm.rank
-        gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+        wire32 = _wire_fp32()
+        kept = _kv_cache_take(process_group, k, v, W, rank)
+        if kept is not None:
+            gather, (k_all, v_all) = None, kept
+        else:
+            gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+        # K/V of every rank are here already: remote steps first, local block beside the all-to-all (the fp32
+        # reduce-scatter wire keeps the local-first order)
+        local_last = gather is None and not wire32
         # per-chunk contributions of THIS rank's queries: slot c holds this rank's dK/dV for the chunk owned by
         # rank c.  Every slot is written exactly once (a "front" step produces only the first half of its
         # chunk: the other half is zero-filled here, r half-chunks instead of the whole buffer), so the dK/dV
         # kernel stores straight into it: fp32 (BWD_KV_OVERWRITE) or the io dtype — no workspace, no reduction
         # pass.  The owner then sums the W arrivals of its chunk in fp32.
-        wire32 = _wire_fp32()
         wdt = torch.float32 if wire32 else q.dtype
         # k, v that are one packed kv tensor: the contributions are packed the same way and travel as ONE buffer
         packed = packed_pair(k, v) is not None
@@ -226,12 +273,18 @@ def zigzag_ring_flash_attn_backward(
             return dict(dk=dk_all[src][:, rows], dv=dv_all[src][:, rows])
 
         full = slice(None)
-        be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-               dq_acc=dq, acc_init=True, deterministic=deterministic, **slots(rank, full))   # beside the all-gather
-        gather.wait()
+        if not local_last:
+            be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
+                   dq_acc=dq, acc_init=True, deterministic=deterministic, **slots(rank, full))   # beside the all-gather
+            if gather is not None:
+                gather.wait()
+        elif rank == 0:
+            dq[:, :half].zero_()             # every remote step of rank 0 covers the second half of the queries only
+        first = local_last                   # the first kernel that touches dq initialises the rows it covers
         for step in range(1, W):
             src = (rank - step) % W
             ks, vs = k_all[src], v_all[src]
+            init, first = first, False
             if step <= rank:
                 if packed:
                     dkv_all[src][:, half:].zero_()
@@ -239,11 +292,11 @@ def zigzag_ring_flash_attn_backward(
                     dk_all[src][:, half:].zero_()
                     dv_all[src][:, half:].zero_()
                 be.bwd(dout, q, ks[:, :half], vs[:, :half], softmax_lse, delta, softmax_scale=softmax_scale,
-                       causal=False, dq_acc=dq, acc_init=False, deterministic=deterministic,
+                       causal=False, dq_acc=dq, acc_init=init, deterministic=deterministic,
                        phases=_C.BWD_KV_OVERWRITE, **slots(src, slice(0, half)))
             else:
                 be.bwd(dout[:, half:], q[:, half:], ks, vs, softmax_lse[:, :, half:], delta[:, :, half:],
-                       softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:], acc_init=False,
+                       softmax_scale=softmax_scale, causal=False, dq_acc=dq[:, half:], acc_init=init,
                        deterministic=deterministic, phases=_C.BWD_KV_OVERWRITE, **slots(src, full))
         if wire32:
             sums = [torch.empty((c.shape[0] // W,) + tuple(c.shape[1:]), dtype=torch.float32, device=q.device) for c in cats]
@@ -257,9 +310,20 @@ def zigzag_ring_flash_attn_backward(
             return dq_out, be.cast(sums[0], q.dtype), be.cast(sums[1], q.dtype)
         ins = [torch.empty_like(c) for c in cats]
         works = [all_to_all_async(i_, c, group=process_group) for i_, c in zip(ins, cats)]
+        if local_last:
+            # the local causal block runs beside the exchange; its contribution (this rank's own chunk) does not
+            # travel: it is written next to the arrivals once they are in (the self chunk of the all-to-all
+            # carried nothing)
+            own = [torch.empty((c.shape[0] // W,) + tuple(c.shape[1:]), dtype=wdt, device=q.device) for c in cats]
+            own_kv = (dict(dk=own[0].select(-3, 0), dv=own[0].select(-3, 1)) if packed else dict(dk=own[0], dv=own[1]))
+            be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
+                   dq_acc=dq, acc_init=False, deterministic=deterministic, **own_kv)
         dq_out = be.cast(dq, q.dtype)                                      # runs beside the exchange
         for w_ in works:
             w_.wait()
+        if local_last:
+            for i_, o_ in zip(ins, own):
+                i_.view((W,) + tuple(o_.shape))[rank].copy_(o_)
         # owner side: sum the W arrivals of this rank's chunk in fp32, straight into the caller's gradient
         # buffers when it provided them (the packed kv gradient of the kvpacked entry points)
         _, dk, dv = _grad_buffers(out_grads, None, k, v)

@@ -33,6 +33,47 @@ def test_zigzag_fp32_wire_matches_golden(W, monkeypatch):
     assert not errs, "\n".join(errs)
 
 
+@pytest.mark.parametrize("W", [2, 4])
+def test_zigzag_gather_without_the_kv_cache_matches_golden(W, monkeypatch):
+    """RFA_ZIGZAG_KV_CACHE=0: the backward gathers K/V again and keeps the local-block-first order (the default —
+    K/V kept from the forward, remote steps first, local block beside the all-to-all — is what the tests above
+    run)."""
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")
+    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE", "0")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
+def test_kv_cache_entries_are_matched_and_bounded(monkeypatch):
+    """the forward -> backward K/V cache of the zigzag gather form: taken exactly once, missed after an in-place
+    update of k, evicted oldest-first beyond RFA_ZIGZAG_KV_CACHE_BYTES, switched off by RFA_ZIGZAG_KV_CACHE=0"""
+    import torch
+    from ring_flash_attn import zigzag_ring_flash_attn as Z
+
+    Z._KV_CACHE.clear()
+    k, v = torch.randn(1, 16, 2, 8), torch.randn(1, 16, 2, 8)
+    ka, va = torch.randn(2, 1, 16, 2, 8), torch.randn(2, 1, 16, 2, 8)
+    Z._kv_cache_put(None, k, v, 2, 0, ka, va)
+    got = Z._kv_cache_take(None, k, v, 2, 0)
+    assert got is not None and got[0] is ka and Z._kv_cache_take(None, k, v, 2, 0) is None
+    Z._kv_cache_put(None, k, v, 2, 0, ka, va)
+    k.add_(1.0)                                                   # version bump: the gathered copy is stale
+    assert Z._kv_cache_take(None, k, v, 2, 0) is None
+    Z._KV_CACHE.clear()
+    entry = 2 * 2 * k.numel() * k.element_size()
+    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE_BYTES", str(2 * entry))
+    ks = [torch.randn(1, 16, 2, 8) for _ in range(3)]
+    for t in ks:
+        Z._kv_cache_put(None, t, v, 2, 0, ka, va)
+    assert len(Z._KV_CACHE) == 2 and Z._kv_cache_take(None, ks[0], v, 2, 0) is None      # oldest evicted
+    assert Z._kv_cache_take(None, ks[2], v, 2, 0) is not None
+    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE", "0")
+    Z._kv_cache_put(None, ks[0], v, 2, 0, ka, va)
+    assert Z._kv_cache_take(None, ks[0], v, 2, 0) is None
+    Z._KV_CACHE.clear()
+
+
 def test_exchange_mode_auto_threshold(monkeypatch):
     """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
     import torch
