@@ -74,6 +74,31 @@ def test_kv_cache_entries_are_matched_and_bounded(monkeypatch):
     Z._KV_CACHE.clear()
 
 
+def test_packed_pair_recognises_only_adjacent_halves_of_one_buffer():
+    """_common.packed_pair: the kv argument of the kvpacked entry points (dense and varlen) and its gradient are
+    moved / summed as ONE buffer; anything else (separate tensors, qkv-packed slices, swapped halves, a
+    non-contiguous parent) is not"""
+    import torch
+    from ring_flash_attn._common import packed_pair
+
+    kv = torch.randn(2, 16, 2, 3, 8)
+    got = packed_pair(kv[:, :, 0], kv[:, :, 1])
+    assert got is not None and got.shape == kv.shape and got.data_ptr() == kv.data_ptr() and torch.equal(got, kv)
+    kvt = torch.randn(40, 2, 3, 8)                                    # packed sequences (T, 2, Hk, D)
+    got = packed_pair(kvt[:, 0], kvt[:, 1])
+    assert got is not None and torch.equal(got, kvt)
+    off = torch.randn(3, 2, 16, 2, 3, 8)[1]                           # a contiguous sub-block with a storage offset
+    got = packed_pair(off[:, :, 0], off[:, :, 1])
+    assert got is not None and torch.equal(got, off)
+    assert packed_pair(kv[:, :, 1], kv[:, :, 0]) is None              # swapped
+    assert packed_pair(kv[:, :, 0].contiguous(), kv[:, :, 1].contiguous()) is None
+    qkv = torch.randn(2, 16, 3, 3, 8)
+    assert packed_pair(qkv[:, :, 1], qkv[:, :, 2]) is None            # row stride 3 Hk D: not a kv pair
+    wide = torch.randn(2, 16, 2, 3, 16)[..., :8]                      # head_dim slice of a wider buffer
+    assert packed_pair(wide[:, :, 0], wide[:, :, 1]) is None
+    assert packed_pair(kv[:, ::2, 0], kv[:, ::2, 1]) is None          # strided rows
+
+
 def test_exchange_mode_auto_threshold(monkeypatch):
     """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
     import torch
