@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as MG
 
 
-@pytest.mark.parametrize("W", [2, 4, 8])
+@pytest.mark.parametrize("W", [2, 3, 4, 6, 8])
 def test_schedules_match_reference_golden(W):
     names = [n for n, c in MG.CASES.items() if c["W"] == W]
     assert names
@@ -22,7 +22,7 @@ def test_schedules_match_reference_golden(W):
     assert not errs, "\n".join(errs)
 
 
-@pytest.mark.parametrize("W", [2, 4, 8])
+@pytest.mark.parametrize("W", [2, 3, 4, 8])
 def test_zigzag_fp32_wire_matches_golden(W, monkeypatch):
     """gather exchange with fp32 dK/dV contributions + reduce-scatter (RFA_DKV_WIRE=fp32; the default sends the
     io dtype and sums at the owner, exercised by the test above)."""
@@ -117,7 +117,7 @@ def test_exchange_mode_auto_threshold(monkeypatch):
     assert exchange_mode(big, 8) == "gather"
 
 
-@pytest.mark.parametrize("W", [2, 4, 8])
+@pytest.mark.parametrize("W", [2, 3, 4, 6, 8])
 def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
     """RFA_ZIGZAG_EXCHANGE=ring (the reference's hop-by-hop protocol; small shapes default to the mesh-aware
     gather form exercised by the test above) gives the same golden results."""
@@ -250,7 +250,7 @@ def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
         backend.set_backend(None)
 
 
-@pytest.mark.parametrize("W", [2, 4])
+@pytest.mark.parametrize("W", [2, 3, 4, 6])
 def test_llama3_unfused_groups_match_golden(W, monkeypatch):
     """RFA_LLAMA3_GATHER_MAX_BYTES=0 disables the super-group fusion: one all-gather / launch / reduce-scatter
     per `heads_k_stride` group, double-buffered (the default fuses every group of these small cases into one)."""
