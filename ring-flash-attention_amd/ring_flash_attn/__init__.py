@@ -36,6 +36,14 @@ from .stripe_flash_attn import (
     stripe_flash_attn_kvpacked_func,
     stripe_flash_attn_qkvpacked_func,
 )
+# beyond the reference (its README.md:131 lists this entry as a TODO): llama3-style context parallelism over a
+# zigzag-balanced split of the packed token stream
+from .zigzag_llama3_flash_attn_varlen import (
+    zigzag_llama3_flash_attn_prepare_cu_seqlens,
+    zigzag_llama3_flash_attn_varlen_func,
+    zigzag_llama3_flash_attn_varlen_kvpacked_func,
+    zigzag_llama3_flash_attn_varlen_qkvpacked_func,
+)
 from .adapters import (
     substitute_hf_flash_attn,
     update_ring_flash_attn_params,

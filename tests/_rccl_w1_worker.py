@@ -99,6 +99,23 @@ def main(port):
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3", llama3=True)
     os.environ["RFA_LLAMA3_GATHER_MAX_BYTES"] = "0"          # one K/V head group per collective
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3[unfused]", llama3=True)
+    # zigzag_llama3 (all-gather + re-order to stream order + fp32 reduce-scatter)
+    q = torch.randn(T, H, D, generator=g).to(BF)
+    k = torch.randn(T, Hk, D, generator=g).to(BF)
+    v = torch.randn(T, Hk, D, generator=g).to(BF)
+    do = torch.randn(T, H, D, generator=g).to(BF)
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, maxlen, maxlen, 0.0, scale, True)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu, cu, maxlen, maxlen, 0.0, scale, True)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out, lse, _ = R.zigzag_llama3_flash_attn_varlen_func(qd, kd, vd, cu, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    torch.cuda.synchronize()
+    check("zigzag_llama3.out", out, ro, 2e-2)
+    check("zigzag_llama3.lse", lse, rl, 1e-3)
+    for n, a, b in (("dq", qd.grad, rdq), ("dk", kd.grad, rdk), ("dv", vd.grad, rdv)):
+        check(f"zigzag_llama3.{n}", a, b, 1e-2, 2e-2)
+    print("ok zigzag_llama3", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     print("ALL OK", flush=True)

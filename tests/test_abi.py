@@ -129,6 +129,10 @@ def test_public_api_surface():
                    "local_k_slice"] + tail
     assert list(inspect.signature(r.llama3_flash_attn_prepare_cu_seqlens).parameters) == ["cu_seqlens", "causal", "rank", "world_size"]
     assert callable(r.substitute_hf_flash_attn) and callable(r.update_ring_flash_attn_params)
+    # beyond the reference (its README TODO): zigzag_llama3 takes the GLOBAL cu_seqlens
+    sig = list(inspect.signature(r.zigzag_llama3_flash_attn_varlen_func).parameters)
+    assert sig == ["q", "k", "v", "cu_seqlens", "heads_k_stride"] + tail
+    assert list(inspect.signature(r.zigzag_llama3_flash_attn_prepare_cu_seqlens).parameters) == ["cu_seqlens", "causal", "rank", "world_size"]
 
 
 def test_prepare_cu_seqlens_golden(golden):

@@ -155,3 +155,30 @@ def test_config5_hf_adapter_qwen3(W, layers, cu):
         er = (grads[n] - g).abs().max().item() / denom
         eb = (bf_grads[n] - g).abs().max().item() / denom
         assert er <= 2 * eb + 2e-2, f"{n}: ring {er:.3e} vs eager-bf16 {eb:.3e}"
+
+
+@pytest.mark.parametrize("W,case", [
+    (2, dict(cu=[0, 700, 701, 2048], H=4, Hk=2, D=128, causal=True, seed=71)),
+    (4, dict(cu=[0, 1000, 3000, 4096], H=4, Hk=2, D=128, causal=True, seed=72, packed=True)),
+])
+def test_zigzag_llama3_hip_matches_full_packed_attention(W, case):
+    """zigzag_llama3_flash_attn_varlen_func on the HIP kernels (W ranks sharing the GPU) against plain packed-sequence
+    attention over the whole stream (CPU oracle)"""
+    import _zz_llama3_worker as ZW
+    from conftest import free_port
+    from oracle import flash_attn_ref as O
+
+    q, k, v, do = ZW.make_inputs(case)
+    cu = torch.tensor(case["cu"], dtype=torch.int32)
+    scale = case["D"] ** -0.5
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, 0.0, scale, True)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu, cu, 0, 0, 0.0, scale, True)
+    res = ZW.run_world(W, case, use_hip=True, port=free_port())
+    for r, got in enumerate(res):
+        assert not isinstance(got, str), got
+        _check(f"r{r}.out", got["out"], ZW.shard(ro.float(), r, W), 2e-2)
+        _check(f"r{r}.lse", got["lse"], ZW.shard(rl.transpose(0, 1).contiguous(), r, W).transpose(0, 1), 1e-3)
+        _check(f"r{r}.dq", got["dq"], ZW.shard(rdq.float(), r, W), 1e-2, 2e-2)
+        _check(f"r{r}.dk", got["dk"], ZW.shard(rdk.float(), r, W), 1e-2, 2e-2)
+        _check(f"r{r}.dv", got["dv"], ZW.shard(rdv.float(), r, W), 1e-2, 2e-2)

@@ -381,3 +381,40 @@ def test_single_rank_window_through_public_api(single_rank_group):
         assert (out.double() - ref).abs().max() < 2e-2 and qkv.grad is not None
     finally:
         backend.set_backend(None)
+
+
+@pytest.mark.parametrize("W,case", [
+    (1, dict(cu=[0, 40, 41, 128], H=4, Hk=2, D=32, causal=True, seed=61)),
+    (2, dict(cu=[0, 22, 75, 128], H=4, Hk=2, D=32, causal=True, seed=62)),
+    (3, dict(cu=[0, 50, 51, 132], H=2, Hk=2, D=32, causal=True, seed=63, packed=True)),
+    (4, dict(cu=[0, 128], H=4, Hk=1, D=64, causal=True, seed=64)),
+    (2, dict(cu=[0, 30, 100, 128], H=2, Hk=2, D=32, causal=False, seed=65)),
+    (2, dict(cu=[0, 60, 128], H=2, Hk=1, D=32, causal=True, window=(16, 0), seed=66)),
+])
+def test_zigzag_llama3_matches_full_packed_attention(W, case):
+    """zigzag_llama3_flash_attn_varlen_func (the reference's README TODO, built here): every rank holds slices r and
+    2W-1-r of the packed stream; the result must be plain packed-sequence attention over the whole stream.  Sequence
+    boundaries inside slices, 1-token sequences, one sequence spanning all slices, GQA, non-causal, a window."""
+    import torch
+    import _zz_llama3_worker as ZW
+    from oracle import flash_attn_ref as O
+
+    q, k, v, do = ZW.make_inputs(case)
+    cu = torch.tensor(case["cu"], dtype=torch.int32)
+    scale = case["D"] ** -0.5
+    win = tuple(case.get("window", (-1, -1)))
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, 0.0, scale, case["causal"],
+                                                window_size_left=win[0], window_size_right=win[1])
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu, cu, 0, 0, 0.0, scale, case["causal"],
+                                  window_size_left=win[0], window_size_right=win[1])
+    res = ZW.run_world(W, case, use_hip=False, port=free_port())
+    for r, got in enumerate(res):
+        assert not isinstance(got, str), got
+        for name, ref, tol in (("out", ro, (2e-2, 0.0)), ("dq", rdq, (3e-2, 1e-2)), ("dk", rdk, (3e-2, 1e-2)), ("dv", rdv, (3e-2, 1e-2))):
+            want = ZW.shard(ref.float(), r, W)
+            diff = (got[name] - want).abs().max().item()
+            assert diff <= tol[0] + tol[1] * want.abs().max().item(), f"W={W} r{r} {name}: {diff:.3e}"
+        want = ZW.shard(rl.transpose(0, 1).contiguous(), r, W).transpose(0, 1)
+        assert (got["lse"] - want).abs().max().item() <= 1e-4, f"W={W} r{r} lse"
+
