@@ -12,13 +12,37 @@ H2D copy + nonzero sync each time) and a TorchScript loop with .item() for the l
 kernels take `q_half` / `k_half` selectors and do the offset arithmetic themselves
 (csrc/rfa_common.hpp: resolve_span): no gathers, no copies, no host syncs; results land
 directly in the right rows of the full-size accumulators.
+
+Exchange forms (RFA_ZIGZAG_VARLEN_EXCHANGE = ring | gather, default ring): `ring` is the reference's hop-by-hop
+protocol; `gather` is the mesh-aware form of the dense zigzag path (zigzag_ring_flash_attn.py) for packed
+sequences — one all-gather of K/V beside the local block, every rank's dK/dV contribution for the rows of rank
+c written into slot c (a "front" step fills only the front half of every sequence: the slot is zeroed first),
+one all-to-all, fp32 sum of the W arrivals at the owner (rfa_sum_slots).  Same kernels, same step order.
 """
+import os
+
 import torch
 
 from . import _C
 from .backend import get_backend, HALF_FRONT, HALF_BACK
-from .utils import RingComm, single_rank
+from .utils import AllGatherComm, RingComm, all_to_all_async, single_rank
 from ._api import make_autograd_function, make_varlen_api, _grad_buffers
+
+
+def varlen_exchange_mode() -> str:
+    mode = os.environ.get("RFA_ZIGZAG_VARLEN_EXCHANGE", "ring").lower()
+    if mode not in ("ring", "gather"):
+        raise ValueError(f"RFA_ZIGZAG_VARLEN_EXCHANGE must be 'ring' or 'gather', got {mode!r}")
+    return mode
+
+
+def _gather_kv(process_group, k, v, world):
+    comm = AllGatherComm(process_group)
+    k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
+    v_cat = torch.empty_like(k_cat)
+    comm.all_gather(k_cat, k.contiguous())
+    comm.all_gather(v_cat, v.contiguous())
+    return comm, k_cat.view((world,) + tuple(k.shape)), v_cat.view((world,) + tuple(v.shape))
 
 
 def get_half_index(cu_seqlens, *, front: bool):
@@ -85,6 +109,20 @@ def zigzag_ring_flash_attn_varlen_forward(
 
     out_acc = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((H, T), dtype=torch.float32, device=q.device)
+
+    if varlen_exchange_mode() == "gather":
+        W, rank = comm.world_size, comm.rank
+        gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,                  # beside the all-gather
+               out_acc=out_acc, lse_acc=lse_acc, acc_init=True, **vl)
+        gather.wait()
+        for step in range(1, W):
+            src = (rank - step) % W
+            halves = dict(k_half=HALF_FRONT) if step <= rank else dict(q_half=HALF_BACK)
+            be.fwd(q, k_all[src], v_all[src], softmax_scale=softmax_scale, causal=False,
+                   out_acc=out_acc, lse_acc=lse_acc, **halves, **vl)
+        return be.cast(out_acc, q.dtype), lse_acc
+
     next_k, next_v = None, None
     for step in range(comm.world_size):
         if step + 1 != comm.world_size:
@@ -148,6 +186,40 @@ def zigzag_ring_flash_attn_varlen_backward(
     dq = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)
     dv = torch.empty(v.shape, dtype=torch.float32, device=q.device)
+
+    if varlen_exchange_mode() == "gather":
+        W, rank = kv_comm.world_size, kv_comm.rank
+        gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+        # slot c: this rank's dK/dV contribution (io dtype) for the rows of rank c
+        dk_all = torch.empty((W,) + tuple(k.shape), dtype=q.dtype, device=q.device)
+        dv_all = torch.empty_like(dk_all)
+        be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,       # beside the all-gather
+               dq_acc=dq, acc_init=True, dk=dk_all[rank], dv=dv_all[rank], deterministic=deterministic, **vl)
+        gather.wait()
+        for step in range(1, W):
+            src = (rank - step) % W
+            if step <= rank:
+                halves = dict(k_half=HALF_FRONT)     # only the front half of every sequence receives a contribution
+                dk_all[src].zero_()
+                dv_all[src].zero_()
+            else:
+                halves = dict(q_half=HALF_BACK)
+            be.bwd(dout, q, k_all[src], v_all[src], softmax_lse, delta, softmax_scale=softmax_scale, causal=False,
+                   dq_acc=dq, acc_init=False, dk=dk_all[src], dv=dv_all[src], deterministic=deterministic,
+                   **halves, **vl)
+        dk_in, dv_in = torch.empty_like(dk_all), torch.empty_like(dv_all)
+        works = [all_to_all_async(dk_in.view((-1,) + tuple(k.shape[1:])), dk_all.view((-1,) + tuple(k.shape[1:])),
+                                  group=process_group),
+                 all_to_all_async(dv_in.view((-1,) + tuple(v.shape[1:])), dv_all.view((-1,) + tuple(v.shape[1:])),
+                                  group=process_group)]
+        dq_out = be.cast(dq, q.dtype)                                                  # beside the exchange
+        for w_ in works:
+            w_.wait()
+        _, dk_out, dv_out = _grad_buffers(out_grads, None, k, v)
+        be.sum_slots(dk_in, dk_out)
+        be.sum_slots(dv_in, dv_out)
+        return dq_out, dk_out, dv_out
+
     next_dk, next_dv = None, None
     next_k, next_v = None, None
     dk_comm_buffer, dv_comm_buffer = None, None

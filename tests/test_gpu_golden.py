@@ -21,3 +21,18 @@ def test_multirank_hip_matches_reference_golden(W):
     names = [n for n, c in MG.CASES.items() if c["W"] == W]
     errs = RW.run_world(W, names, use_hip=True, port=free_port())
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_zigzag_varlen_gather_exchange_hip_matches_golden(W, monkeypatch):
+    """RFA_ZIGZAG_VARLEN_EXCHANGE=gather (the mesh-aware form for packed sequences; default: the ring protocol) on the
+    HIP kernels: io-dtype dK/dV slots with half-sequence selection, all-to-all, rfa_sum_slots"""
+    import _ring_worker as RW
+    import make_golden as MG
+    from conftest import free_port
+
+    monkeypatch.setenv("RFA_ZIGZAG_VARLEN_EXCHANGE", "gather")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag_varlen"]
+    assert names
+    errs = RW.run_world(W, names, use_hip=True, port=free_port())
+    assert not errs, "\n".join(errs)

@@ -99,6 +99,16 @@ def test_packed_pair_recognises_only_adjacent_halves_of_one_buffer():
     assert packed_pair(kv[:, ::2, 0], kv[:, ::2, 1]) is None          # strided rows
 
 
+@pytest.mark.parametrize("W", [2, 3, 4])
+def test_zigzag_varlen_gather_exchange_matches_golden(W, monkeypatch):
+    """RFA_ZIGZAG_VARLEN_EXCHANGE=gather: the dense zigzag path's mesh-aware exchange for packed sequences"""
+    monkeypatch.setenv("RFA_ZIGZAG_VARLEN_EXCHANGE", "gather")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag_varlen"]
+    assert names
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
 def test_exchange_mode_auto_threshold(monkeypatch):
     """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
     import torch
