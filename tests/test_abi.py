@@ -243,3 +243,25 @@ def test_backward_plan_is_a_function_of_the_shapes(built, monkeypatch):
     monkeypatch.setenv("RFA_DKDV_NSPLIT", "3")
     assert ws(args(1, 1024, 1024, 4, 2)) == 3 * unit(1024, 2)
 
+
+def test_bench_accounting_matches_the_survey():
+    """bench.py's algorithmic FLOP and byte accounting (no GPU): SURVEY.md section 8(d) fixes the headline at
+    3.5 * 2*B*H*D*8192^2 * W = 1.9242e12 * W FLOP per GPU and iteration (causal counted as half, bwd = 2.5 fwd)
+    and 100 %-MFMA ceilings of 1299 / 650 / 325 / 162 it/s at W = 1 / 2 / 4 / 8"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for w, ceiling in ((1, 1299), (2, 650), (4, 325), (8, 162)):
+        per_gpu = 3.5 * b.fwd_flops_per_gpu("zigzag", w)
+        assert abs(per_gpu - 1.9242e12 * w) / (1.9242e12 * w) < 1e-3
+        assert abs(b.MFMA_PEAK_TFLOPS * 1e12 / per_gpu - ceiling) < 1.0
+    m = 2 * 8192 * 8 * 128 * 2                                   # K + V of one rank, bf16, Hk = 8 (32 MiB)
+    assert m == 32 << 20
+    # reference protocol (BASELINE.md section 2): (W-1) M forward, (W-1) M + W * 2M (fp32 dK/dV) backward
+    assert b.comm_bytes_per_iter("ring", False, 8, 8) == 7 * m + 7 * m + 8 * 2 * m
+    # gather form: one all-gather (kept for the backward) + the bf16 contributions of the other W-1 chunks
+    assert b.comm_bytes_per_iter("gather", False, 8, 8) == 7 * m + 7 * m
+    assert b.comm_bytes_per_iter("gather", True, 8, 8) == 7 * m + 7 * 2 * m
+
