@@ -80,7 +80,14 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
             q.requires_grad_(True); k.requires_grad_(True); v.requires_grad_(True)
             kw = dict(dropout_p=0.0, window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=True)
             kind = c["kind"]
-            if kind == "zigzag":
+            if kind == "zigzag" and os.environ.get("RFA_TEST_CHECKPOINT") == "1":
+                # activation checkpointing: the first forward runs without grad (nothing is kept for a backward), the
+                # recomputation forward is the one whose gathered K/V the backward reuses
+                from torch.utils.checkpoint import checkpoint
+
+                out, lse, _ = checkpoint(lambda a, b_, c_: R.zigzag_ring_flash_attn_func(a, b_, c_, causal=True, **kw),
+                                         q, k, v, use_reentrant=False)
+            elif kind == "zigzag":
                 out, lse, _ = R.zigzag_ring_flash_attn_func(q, k, v, causal=True, **kw)
             elif kind == "ring":
                 out, lse, _ = R.ring_flash_attn_func(q, k, v, causal=c["causal"], **kw)

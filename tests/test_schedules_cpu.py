@@ -45,6 +45,16 @@ def test_zigzag_gather_without_the_kv_cache_matches_golden(W, monkeypatch):
     assert not errs, "\n".join(errs)
 
 
+def test_zigzag_under_activation_checkpointing_matches_golden(monkeypatch):
+    """torch.utils.checkpoint around the zigzag call (gather form): forward without grad, recomputation forward,
+    backward that reuses the recomputation's gathered K/V"""
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")
+    monkeypatch.setenv("RFA_TEST_CHECKPOINT", "1")
+    names = [n for n, c in MG.CASES.items() if c["W"] == 4 and c["kind"] == "zigzag"]
+    errs = RW.run_world(4, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
 def test_kv_cache_entries_are_matched_and_bounded(monkeypatch):
     """the forward -> backward K/V cache of the zigzag gather form: taken exactly once, missed after an in-place
     update of k, evicted oldest-first beyond RFA_ZIGZAG_KV_CACHE_BYTES, switched off by RFA_ZIGZAG_KV_CACHE=0"""
