@@ -13,7 +13,7 @@ inputs are the caller's LOCAL shard.
 import torch
 
 from ._common import _prep_qkv, _as_cu
-from .utils import backward_expected
+from .utils import backward_expected, grad_mode_at_call
 
 
 def _opaque(fn):
@@ -50,7 +50,8 @@ def _compilable(fn, lower):
     def public(*args, **kwargs):
         if torch.compiler.is_compiling() and _single_rank(kwargs.get("group", None)):
             return lower(*args, **kwargs)
-        return eager(*args, **kwargs)
+        with grad_mode_at_call():
+            return eager(*args, **kwargs)
 
     return public
 

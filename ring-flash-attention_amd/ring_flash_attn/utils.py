@@ -135,7 +135,22 @@ class backward_expected:
 
 
 def is_backward_expected() -> bool:
-    return _BACKWARD_EXPECTED
+    return _BACKWARD_EXPECTED and _GRAD_MODE_AT_CALL
+
+
+# grad mode at the moment the PUBLIC function was called (inside autograd.Function.forward it is always off, and
+# needs_input_grad only reflects the tensors' requires_grad flags): torch.no_grad() inference keeps nothing
+_GRAD_MODE_AT_CALL = True
+
+
+class grad_mode_at_call:
+    def __enter__(self):
+        global _GRAD_MODE_AT_CALL
+        self.prev, _GRAD_MODE_AT_CALL = _GRAD_MODE_AT_CALL, torch.is_grad_enabled()
+
+    def __exit__(self, *exc):
+        global _GRAD_MODE_AT_CALL
+        _GRAD_MODE_AT_CALL = self.prev
 
 
 def group_rank_world(process_group):

@@ -55,6 +55,18 @@ def test_zigzag_under_activation_checkpointing_matches_golden(monkeypatch):
     assert not errs, "\n".join(errs)
 
 
+def test_kv_cache_follows_the_autograd_state():
+    """the gathered K/V are kept exactly when a backward will follow: not under torch.no_grad(), not for inputs
+    without requires_grad; and the backward consumes the entry"""
+    import torch.multiprocessing as mp
+    import _kv_cache_worker as KW
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(KW.run, args=(2, free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == [1, 0, 0, 0] and ret[1] == [1, 0, 0, 0], dict(ret)
+
+
 def test_kv_cache_entries_are_matched_and_bounded(monkeypatch):
     """the forward -> backward K/V cache of the zigzag gather form: taken exactly once, missed after an in-place
     update of k, evicted oldest-first beyond RFA_ZIGZAG_KV_CACHE_BYTES, switched off by RFA_ZIGZAG_KV_CACHE=0"""
