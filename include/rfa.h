@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RFA_ABI_VERSION 3
+#define RFA_ABI_VERSION 4
 
 typedef enum {
   RFA_OK = 0,
@@ -139,9 +139,11 @@ typedef struct {
   float *dq_acc, *dk_acc, *dv_acc;
   rfa_strides dq_acc_st, dk_acc_st, dv_acc_st;
   int32_t acc_init;
-  /* workspace for dK/dV partials (already summed over the query heads of a K/V group), io dtype,
-   * rfa_bwd_workspace_bytes() bytes: 2 * total_k*Hk*D elements, times the number of workgroups that share
-   * a key block's query range when the 256-key kernel form is used (a function of the shapes only).
+  /* workspace for dK/dV partials (already summed over the query heads of a K/V group),
+   * rfa_bwd_workspace_bytes() bytes.  Unsplit launches: 2 * total_k*Hk*D elements of the io dtype (one
+   * rounding per block, the rounding point of flash_attn's block gradients).  Launches whose key blocks
+   * share their query range between `nsplit` workgroups (256-key kernel form, see dkdv_form): nsplit fp32
+   * partials per element, summed and rounded ONCE by the reduction pass.
    * ALWAYS size it with rfa_bwd_workspace_bytes(); may be NULL whenever that returns 0 (single-phase
    * calls that write dk/dv or overwrite dk_acc/dv_acc on launches that need no such split). */
   void *workspace;
@@ -168,7 +170,17 @@ typedef struct {
    * (cu_seqlens: the scratch is then laid out with the extents of the longest sequence, Sq / Sk = max_seqlen). */
   void *ds_scratch;
   int32_t window, window_left, window_right; /* as in rfa_fwd_args (a bounded window_left is not eligible for ds_scratch) */
+  /* dK/dV launch plan (ABI 4: part of the call instead of process environment, so that the COMPUTE and the
+   * REDUCE phase of one backward — and rfa_bwd_workspace_bytes() — can never disagree).
+   *   dkdv_form   RFA_DKDV_AUTO: chosen from the shapes; RFA_DKDV_128: a workgroup owns 128 keys;
+   *               RFA_DKDV_256: 256 keys (head dim 128 without a window only, otherwise ignored)
+   *   dkdv_nsplit 0: chosen from the shapes; 1..8: workgroups sharing the query range of a key block
+   *               (256-key form only)
+   * A zero-initialised struct means "auto".  rfa_bwd_plan() reports what a call will run. */
+  int32_t dkdv_form, dkdv_nsplit;
 } rfa_bwd_args;
+
+enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };
 
 enum {
   RFA_BWD_ALL = 0,
@@ -208,6 +220,9 @@ const char *rfa_strerror(int status);
 int rfa_fwd(const rfa_fwd_args *args, void *stream);
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
+/* the launch plan of a call: *form = RFA_DKDV_128 / RFA_DKDV_256, *nsplit >= 1, *five_gemm = 1 when the call
+ * (with its ds_scratch) runs the dS-spill form.  Pure function of the arguments. */
+int rfa_bwd_plan(const rfa_bwd_args *args, int32_t *form, int32_t *nsplit, int32_t *five_gemm);
 /* bytes of ds_scratch the call would use (B*H*ceil(Sq/32)*ceil(Sk/32)*2048; packed input: B sequences, Sq / Sk =
  * max_seqlen_q / _k; with q_half / k_half: ceil(S/2) instead of S), or 0 if it is not eligible */
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args *args);

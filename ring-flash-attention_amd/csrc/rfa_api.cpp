@@ -4,8 +4,6 @@
 #include "../../include/rfa.h"
 #include "rfa_kernels.hpp"
 
-#include <cstdlib>
-
 using namespace rfa;
 
 namespace {
@@ -125,23 +123,17 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
   return a->dk_acc != nullptr && bwd_single_phase(a) && (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE));
 }
 
-// Which dK/dV kernel form a call runs (a pure function of the call's shapes, so that rfa_bwd_workspace_bytes, a
-// BWD_COMPUTE and its BWD_REDUCE call agree): the 256-key workgroup form needs head dim 128 and no window; its
-// workgroups are B * Hk * ceil(Sk / 256), so the Q/dO tile range of a key block is shared by up to 4 workgroups
-// until the launch has about two workgroups per CU (a causal launch needs that many for its heavy-first order to
-// balance), each with at least 8 tiles.  Launches that stay small even so run the 128-key form (twice the
-// workgroups).  RFA_DKDV_WIDE=0 / RFA_DKDV_NSPLIT=n override (tuning).
+// Which dK/dV kernel form a call runs — a pure function of the call's arguments (shapes + the dkdv_form /
+// dkdv_nsplit fields), so that rfa_bwd_workspace_bytes, a BWD_COMPUTE and its BWD_REDUCE call agree: the 256-key
+// workgroup form needs head dim 128 and no window; its workgroups are B * Hk * ceil(Sk / 256), so the Q/dO tile
+// range of a key block is shared by up to 4 workgroups until the launch has about two workgroups per CU (a causal
+// launch needs that many for its heavy-first order to balance), each with at least 8 tiles.  Launches that stay
+// small even so run the 128-key form (twice the workgroups).
 struct DkdvPlan { int wide, nsplit; };
-static int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && *e) ? atoi(e) : dflt;
-}
 static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
-  // (read per call: the tests force every form on small shapes)
-  const int env_wide = env_int("RFA_DKDV_WIDE", 1), env_nsplit = env_int("RFA_DKDV_NSPLIT", 0);
   DkdvPlan pl{0, 1};
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-  if (!env_wide || a->D != kHeadDim || win) return pl;
+  if (a->dkdv_form == RFA_DKDV_128 || a->D != kHeadDim || win) return pl;
   const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
   // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) key blocks per K/V head, of which
   // only about total_k / 256 (+ one tail per sequence) are not past the end of their sequence
@@ -153,8 +145,9 @@ static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   const int64_t wgs = kblocks * a->Hk;
   int ns = 1;
   while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 512) ++ns;
-  if (env_nsplit > 0) ns = env_nsplit > 8 ? 8 : env_nsplit;
-  if (wgs * ns < 320 && env_nsplit <= 0) return pl;
+  const bool forced = a->dkdv_form == RFA_DKDV_256;
+  if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
+  if (wgs * ns < 320 && !forced && a->dkdv_nsplit <= 0) return pl;
   pl.wide = 1;
   pl.nsplit = ns;
   return pl;
@@ -171,14 +164,36 @@ static bool bwd_spill_eligible(const rfa_bwd_args* a) {
          !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
 }
 
+// dS scratch rows: packed triangular for dense causal calls (block (qt, kb) is visited iff kb < qt + c), else
+// rectangular, expressed as c >= nKb (rfa_kernels.hpp: ds_row_off)
+static int bwd_ds_c(const rfa_bwd_args* a) {
+  const int nkb = ds_blocks(a->Sk, a->k_half);
+  if (!a->causal || a->cu_seqlens_q != nullptr) return nkb;
+  const int off = eff_len(a->Sk, a->k_half) - eff_len(a->Sq, a->q_half);
+  const int c = ((31 + off) >> 5) + 1;                   // (arithmetic shift: off may be negative)
+  return c > nkb ? nkb : c;
+}
+
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_spill_eligible(a)) return 0;
-  return (int64_t)a->B * a->H * ds_blocks(a->Sq, a->q_half) * ds_blocks(a->Sk, a->k_half) * kDsBlockBytes;
+  const int64_t per_head = ds_row_off(ds_blocks(a->Sq, a->q_half), ds_blocks(a->Sk, a->k_half), bwd_ds_c(a), 1);
+  return (int64_t)a->B * a->H * per_head * kDsBlockBytes;
+}
+
+int rfa_bwd_plan(const rfa_bwd_args* a, int32_t* form, int32_t* nsplit, int32_t* five_gemm) {
+  if (!a) return RFA_ERR_NULL;
+  const DkdvPlan pl = bwd_dkdv_plan(a);
+  if (form) *form = pl.wide ? RFA_DKDV_256 : RFA_DKDV_128;
+  if (nsplit) *nsplit = pl.nsplit;
+  if (five_gemm) *five_gemm = (a->ds_scratch != nullptr && bwd_spill_eligible(a)) ? 1 : 0;
+  return RFA_OK;
 }
 
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
-  return 2 * a->total_k * (int64_t)a->Hk * a->D * 2 * bwd_dkdv_plan(a).nsplit;
+  // unsplit: one io-dtype partial per element; split launches: nsplit fp32 partials
+  const int ns = bwd_dkdv_plan(a).nsplit;
+  return 2 * a->total_k * (int64_t)a->Hk * a->D * (ns > 1 ? 4 * ns : 2);
 }
 
 int rfa_bwd(const rfa_bwd_args* a, void* stream) {
@@ -192,6 +207,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   if ((a->dk_acc == nullptr) != (a->dv_acc == nullptr)) return RFA_ERR_ARGS;
   if (!a->dk_acc && (!a->dk || !a->dv)) return RFA_ERR_NULL;
   if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
+  if (a->dkdv_form < RFA_DKDV_AUTO || a->dkdv_form > RFA_DKDV_256 || a->dkdv_nsplit < 0) return RFA_ERR_ARGS;
   const bool ws = bwd_needs_ws(a);
   if (ws && !a->workspace) return RFA_ERR_NULL;
   if (!aligned16(a->dout) || !aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v))
@@ -234,16 +250,19 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   } else if (ws) {
     // partials: (rows, Hk, nsplit, D) contiguous; dense rows = b*Sk + row (own batch stride).  The kernel addresses
     // K/V head hk of split s at element (hk * nsplit + s) * D of a row, reduce_kernel reads the nsplit entries of
-    // a K/V head as its "group" (G = nsplit, head stride D)
+    // a K/V head as its "group" (G = nsplit, head stride D).  Split launches keep fp32 partials (summed, then
+    // rounded once — the rounding an unsplit launch does); unsplit ones the io dtype.
     const int64_t ns = plan.nsplit;
+    const int64_t esz = ns > 1 ? 4 : 2;
     ws_st.head = a->D;
     ws_st.row = (int64_t)a->Hk * ns * a->D;
     ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->Hk * ns * a->D;
     p.dk = a->workspace;
-    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->Hk * ns * a->D * 2;
+    p.dv = (char*)a->workspace + a->total_k * (int64_t)a->Hk * ns * a->D * esz;
     p.dk_st = ws_st; p.dv_st = ws_st;
     p.dk_st.head = p.dv_st.head = ns * a->D;
     p.kv_split_stride = a->D;
+    p.kv_f32 = p.kv_part_f32 = ns > 1 ? 1 : 0;
   } else {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
@@ -257,6 +276,8 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       // 5-GEMM form: dK/dV kernel first (it stores dS), then dQ streams dS back
       if (!aligned16(a->ds_scratch)) return RFA_ERR_ALIGN;
       p.ds = a->ds_scratch;
+      p.ds_c = bwd_ds_c(a);
+      p.ds_tri = p.ds_c < ds_blocks(a->Sk, a->k_half) ? 1 : 0;
       if (!(a->phases & RFA_BWD_SKIP_DKDV))
         if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
       if (!(a->phases & RFA_BWD_SKIP_DQ))
@@ -269,22 +290,22 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     }
   }
   if (ws && do_reduce) {
-    for (int which = 0; which < 2; ++which) {
-      ReduceParams r{};
-      r.src = which ? p.dv : p.dk;
-      r.src_st = ws_st;
-      r.cu_k = a->cu_seqlens_k;
-      r.B = a->B; r.Hk = a->Hk; r.G = plan.nsplit; r.D = a->D; r.Sk = a->Sk;   // query-head groups are already summed
-      r.k_half = a->k_half; r.acc_init = kv_init;
-      if (a->dk_acc) {
-        r.dst_acc = which ? a->dv_acc : a->dk_acc;
-        r.dst_acc_st = cv(which ? a->dv_acc_st : a->dk_acc_st);
-      } else {
-        r.dst = which ? a->dv : a->dk;
-        r.dst_st = cv(which ? a->dv_st : a->dk_st);
-      }
-      if (launch_reduce(r, a->dtype, st)) return RFA_ERR_LAUNCH;
+    // dK and dV in one launch (grid z)
+    ReduceParams r{};
+    r.src = p.dk; r.src2 = p.dv;
+    r.src_st = ws_st;
+    r.src_f32 = plan.nsplit > 1 ? 1 : 0;
+    r.cu_k = a->cu_seqlens_k;
+    r.B = a->B; r.Hk = a->Hk; r.G = plan.nsplit; r.D = a->D; r.Sk = a->Sk;   // query-head groups are already summed
+    r.k_half = a->k_half; r.acc_init = kv_init;
+    if (a->dk_acc) {
+      r.dst_acc = a->dk_acc; r.dst_acc2 = a->dv_acc;
+      r.dst_acc_st = cv(a->dk_acc_st); r.dst_acc2_st = cv(a->dv_acc_st);
+    } else {
+      r.dst = a->dk; r.dst2 = a->dv;
+      r.dst_st = cv(a->dk_st); r.dst2_st = cv(a->dv_st);
     }
+    if (launch_reduce(r, a->dtype, st)) return RFA_ERR_LAUNCH;
   }
   return RFA_OK;
 }

@@ -1,7 +1,7 @@
 // rfa_aux.hip — the HBM-bound side kernels of the ring attention path (gfx950).
 //
 //   preprocess_kernel : Δ = rowsum(dO ∘ O)            (prologue of flash_attn's backward)
-//   reduce_kernel     : dK/dV GQA group sum + fp32 accumulate / cast
+//   reduce_kernel     : dK/dV partial sums (io dtype or fp32 partials) + fp32 accumulate / cast
 //                       (flash_attn's dk_expanded.sum + the reference's `dk += dk_buffer`,
 //                       /root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:182-187)
 //   merge_kernel      : stand-alone online merge of (out, lse) pairs
@@ -44,12 +44,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
 }
 
 // ------------------------------------------------------------------------------------
-// dst[b,row,hk,:] (=|+=) Σ_g src[b,row,hk*G+g,:]
-// one thread per 8-element chunk; grid x = ceil(rows*Hk*16/256), y = B
+// dst[b,row,hk,:] (=|+=) Σ_g src[b,row,hk*G+g,:]   (TS = source type: io dtype, or fp32 partials of a split launch)
+// one thread per 8-element chunk; grid x = ceil(rows*Hk*16/256), y = B, z = tensor (0: src/dst, 1: src2/dst2 —
+// dK and dV of one backward are reduced by ONE launch)
 // ------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, typename TS>
 __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
   const int b = blockIdx.y;
+  const bool second = blockIdx.z != 0;
   const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
   const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int sub = (int)(item & 15);
@@ -62,19 +64,21 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  const T* sp = (const T*)p.src + kbatch * p.src_st.batch + arow * p.src_st.row +
-                (int64_t)(p.g_stride ? hk : hk * p.G) * p.src_st.head + sub * 8;
+  const TS* sp = (const TS*)(second ? p.src2 : p.src) + kbatch * p.src_st.batch + arow * p.src_st.row +
+                 (int64_t)(p.g_stride ? hk : hk * p.G) * p.src_st.head + sub * 8;
   const int64_t gstep = p.g_stride ? p.g_stride : p.src_st.head;
   for (int gq = 0; gq < p.G; ++gq) {
-    const vec8<T> v = *(const vec8<T>*)(sp + (int64_t)gq * gstep);
-    // (flash_attn also rounds each per-head dK/dV to the io dtype before its group sum;
-    //  the partials are io dtype here too, summed in fp32.)
+    // io-dtype partials: flash_attn also rounds each block's dK/dV to the io dtype before they are added up in
+    // fp32 (the reference's `dk += block_dk`); fp32 partials (the workgroups sharing one key block of a split
+    // launch) are rounded once, after the sum
+    const vec8<TS> v = *(const vec8<TS>*)(sp + (int64_t)gq * gstep);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
   }
-  if (p.dst_acc) {
-    float* dp = p.dst_acc + kbatch * p.dst_acc_st.batch + arow * p.dst_acc_st.row +
-                (int64_t)hk * p.dst_acc_st.head + sub * 8;
+  float* dacc = second ? p.dst_acc2 : p.dst_acc;
+  if (dacc) {
+    const Strides st = second ? p.dst_acc2_st : p.dst_acc_st;
+    float* dp = dacc + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + sub * 8;
     f32x4 x0, x1;
     if (p.acc_init) {
 #pragma unroll
@@ -92,7 +96,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
     f32x8 x;
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = acc[e];
-    T* dp = (T*)p.dst + kbatch * p.dst_st.batch + arow * p.dst_st.row + (int64_t)hk * p.dst_st.head + sub * 8;
+    const Strides st = second ? p.dst2_st : p.dst_st;
+    T* dp = (T*)(second ? p.dst2 : p.dst) + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + sub * 8;
     *(vec8<T>*)dp = __builtin_convertvector(x, vec8<T>);
   }
 }
@@ -204,9 +209,14 @@ int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream) {
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream) {
   const int64_t items = (int64_t)p.Sk * p.Hk * 16;
   if (items <= 0 || p.B <= 0) return 0;
-  dim3 grid((unsigned)((items + 255) / 256), (unsigned)p.B);
-  if (dtype == 0) hipLaunchKernelGGL(reduce_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(reduce_kernel<f16_t>, grid, dim3(256), 0, stream, p);
+  dim3 grid((unsigned)((items + 255) / 256), (unsigned)p.B, p.src2 ? 2u : 1u);
+  if (p.src_f32) {
+    if (dtype == 0) hipLaunchKernelGGL((reduce_kernel<bf16_t, float>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((reduce_kernel<f16_t, float>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (dtype == 0) hipLaunchKernelGGL((reduce_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((reduce_kernel<f16_t, f16_t>), grid, dim3(256), 0, stream, p);
+  }
   return ok();
 }
 

@@ -19,8 +19,8 @@
 //                    registers — no per-head partials and no group-reduction pass.  8 waves = 4 key
 //                    blocks x 2 sub-tile parities, or (kWide, the headline launch) 8 key blocks whose
 //                    waves run both sub-tiles; the kWide form may share a key block's query range
-//                    between workgroups (rfa_api.cpp: bwd_dkdv_plan), whose io-dtype partials
-//                    rfa_aux.hip's reduce_kernel sums.  reduce_kernel also serves accumulate /
+//                    between workgroups (rfa_api.cpp: bwd_dkdv_plan), whose fp32 partials
+//                    rfa_aux.hip's reduce_kernel sums (one rounding to the io dtype, like an unsplit launch).  reduce_kernel also serves accumulate /
 //                    two-phase calls (workspace partials -> fp32 accumulators).
 // Lane ownership mirrors the forward kernel (see rfa_common.hpp): after the first GEMM a
 // lane owns one query row (dQ kernel) or one key (dK/dV kernel), and the probabilities go
@@ -380,7 +380,7 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 // LDS-DMA pieces per MFMA are halved (measured: dropping half of the pieces is worth 15 % of the kernel),
 // one barrier per 128 MFMAs per SIMD instead of 64, no exchange at the end.  256-key workgroups are too few for
 // a causal launch at Hk = 8, so the tile range of a key block can be split over p.nsplit workgroups whose
-// partials (io dtype, workspace) are summed by reduce_kernel (rfa_api.cpp).
+// partials (fp32, workspace) are summed by reduce_kernel (rfa_api.cpp).
 template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -609,7 +609,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // slot 16 (key>>2) + 8 i + 4 g + (key&3), i = 0 / 1 for the rows 0-15 / 16-31 of the sub-tile
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
   const int ds_nkb = ds_blocks(p.Sk, p.k_half);  // extents of the longest (half) sequence (= lk, lq when dense): rfa_dqs.hip
-  const int64_t ds_head_bytes = (int64_t)ds_blocks(p.Sq, p.q_half) * ds_nkb * kDsBlockBytes;
+  // rows of the scratch: rectangular (p.ds_c >= ds_nkb) or packed triangular (dense causal), rfa_kernels.hpp
+  const int64_t ds_head_bytes = ds_row_off(ds_blocks(p.Sq, p.q_half), ds_nkb, p.ds_c, 1) * kDsBlockBytes;
   const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kKeys / 32) + kbw);
 
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         auto spill = [&]() {
           if (!kSpill || RFA_SPILL_PROBE == 1) return;
           const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes +
-                            ((int64_t)(2 * j + t) * ds_nkb + ds_kb) * kDsBlockBytes;
+                            (ds_row_off(2 * j + t, ds_nkb, p.ds_c, 1) + ds_kb) * kDsBlockBytes;
           if (RFA_SPILL_PROBE == 4) blk = ds_b + (int64_t)(blockIdx.x * 8 + wave) * kDsBlockBytes;
           const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds0), rb, ds_lane, 0, RFA_SPILL_AUX);
@@ -902,13 +903,8 @@ static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
   if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin>(p, stream);
   return launch_dkdv_t<T, 64, false, false, kWin>(p, stream);
 }
-#ifndef RFA_DKDV1
-#define RFA_DKDV1 0          // 1: head-dim-128, window-free calls run the one-wave-per-SIMD kernel of rfa_bwd1.hip
-                             // (measured slower than the 8-wave form, see the header there: kept as an experiment)
-#endif
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
-  if (RFA_DKDV1 && p.D == 128 && !win) return launch_bwd_dkdv1(p, dtype, stream);
   if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 without a window
     if (p.ds != nullptr)
       return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true>(p, stream)

@@ -14,7 +14,9 @@
 // Scratch layout (written by dkdv_kernel<kSpill>, read here): blocks of 2048 bytes indexed
 //        [batch or packed sequence][q head][qt = query row / 32][kb = key / 32]
 // (row / key counted inside the sequence — or inside its selected half; the qt / kb extents are those of the
-//  longest (half) sequence of the call, ds_blocks() in rfa_kernels.hpp, so packed input needs no offset table)
+//  longest (half) sequence of the call, ds_blocks() in rfa_kernels.hpp, so packed input needs no offset table;
+//  dense causal calls pack the rows triangularly — row qt keeps only the key blocks a causal query block can
+//  see, ds_row_off() / ds_row_len() in rfa_kernels.hpp — which halves the scratch of a square launch)
 // holding dS[32 q][32 keys] as 128 slots of 16 bytes; slot p = 16·(key>>2) + 8·i + 4·g + (key&3) contains
 // (for key = 0..31 of the block, i = 0/1, g = 0/1) the 8 values q = 16i + 4g + {0..3}, 16i + 8 + 4g + {0..3}
 // of that key.  This is the image that makes the transposed LDS read below conflict-free after a
@@ -99,8 +101,14 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   // its first ceil(lq / 32) rows of blocks
   const int nQt = ds_blocks(p.Sq, p.q_half), nKb = ds_blocks(p.Sk, p.k_half);
   // this wave's run of dS blocks: (b, h, qt = qw0 / 32, kb = 0 .. ceil(lk/32)-1), contiguous
-  const char* srun = (const char*)p.ds + ((((int64_t)b * p.H + h) * nQt + (qw0 >> 5)) * nKb) * (int64_t)kDsBlockBytes;
-  const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? ((lk + 31) >> 5) * kDsBlockBytes : 0);
+  // (rows are rectangular, p.ds_c >= nKb, or packed triangular for dense causal calls: rfa_kernels.hpp)
+  const int qt = qw0 >> 5;
+  const char* srun = (const char*)p.ds + (((int64_t)b * p.H + h) * ds_row_off(nQt, nKb, p.ds_c, 1) +
+                                          ds_row_off(qt, nKb, p.ds_c, 1)) * (int64_t)kDsBlockBytes;
+  int run = (lk + 31) >> 5;                              // blocks of this row that can hold data
+  const int rlen = ds_row_len(qt, nKb, p.ds_c, 1);
+  run = run < rlen ? run : rlen;
+  const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? run * kDsBlockBytes : 0);
 
   const int qend = (qwg0 + kDsRows < lq) ? qwg0 + kDsRows : lq;
   int kmax = lk;                                        // (windowed calls are not eligible for the spill path)

@@ -73,22 +73,29 @@ struct BwdParams {
   int wl, wr;          // attention window as in FwdParams (causal: wr = 0)
   int kv_f32;          // dk / dv point to fp32 buffers (overwritten), strides in fp32 elements
   void* ds;            // dS spill scratch (rfa_dqs.hip) or nullptr: dkdv_kernel stores its packed dS blocks there
+  int ds_tri, ds_c;    // scratch rows are triangular (dense causal calls): row qt holds key blocks 0 .. min(nKb, qt + ds_c) - 1
   int nqblk, nkblk;
   float scale;
   // 256-key dK/dV form (dkdv_kernel kWide): the tile range of a key block is shared by nsplit workgroups; split s
   // stores its partial kv_split_stride elements behind split 0's (rfa_api.cpp lays them out for reduce_kernel)
   int wide, nsplit;
   int64_t kv_split_stride;
+  int kv_part_f32;     // dk / dv point to fp32 PARTIALS in the workspace (split launches): fp32 stores, strides in fp32 elements
 };
 
 // dst[b, row, hk, :] (=|+=) sum_g src[b, row, hk*G+g, :]
 struct ReduceParams {
-  const void* src;     // io dtype partials, head index = q head
+  const void* src;     // partials (io dtype, or fp32 when src_f32), head index = q head
   void* dst;           // io dtype (or nullptr)
   float* dst_acc;      // fp32 accumulate target (or nullptr)
+  // optional second tensor reduced by the same launch (blockIdx.z = 1): dV next to dK
+  const void* src2;
+  void* dst2;
+  float* dst_acc2;
   const int32_t* cu_k;
-  Strides src_st, dst_st, dst_acc_st;
+  Strides src_st, dst_st, dst_acc_st, dst2_st, dst_acc2_st;
   int B, Hk, G, D, Sk, k_half, acc_init;
+  int src_f32;
   int64_t g_stride;    // 0: member g of head hk is source head hk*G+g; else: head hk, g_stride elements further per g
 };
 
@@ -109,13 +116,31 @@ int fwd_qrows_per_block();
 int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream);
-// one-wave-per-SIMD dK/dV kernel (rfa_bwd1.hip): head dim 128 exactly, no window; spills dS when p.ds is set
-int launch_bwd_dkdv1(const BwdParams& p, int dtype, hipStream_t stream);
 // dQ = scale * dS K from the dS blocks a preceding launch_bwd_dkdv (with p.ds set) stored; dense, D == 128
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream);
 constexpr int kDsBlockBytes = 2048;
 // rows / columns of 32 x 32 dS blocks the spill scratch reserves per (sequence, head): the longest (half) sequence
 __host__ __device__ inline int ds_blocks(int S, int half) { return ((half ? (S + 1) / 2 : S) + 31) >> 5; }   // one (32 query x 32 key) block of dS in the io dtype
+// Layout of the dS scratch of one (sequence, head): rows qt = query row / 32 of 2 KiB blocks kb = key / 32.
+//   rectangular (packed input, non-causal): every row holds nKb blocks;
+//   triangular (dense causal: block (qt, kb) is visited iff kb < qt + c, c = ((31 + lk - lq) >> 5) + 1): row qt holds
+//   its first ds_row_len(qt) = clamp(qt + c, 0, nKb) blocks, rows packed back to back — half the scratch of a
+//   square causal launch.  ds_row_off(nQt, ...) is the number of blocks per (sequence, head).
+__host__ __device__ inline int ds_row_len(int qt, int nKb, int c, int tri) {
+  if (!tri) return nKb;
+  const int n = qt + c;
+  return n < 0 ? 0 : (n > nKb ? nKb : n);
+}
+__host__ __device__ inline int64_t ds_row_off(int qt, int nKb, int c, int tri) {
+  if (!tri) return (int64_t)qt * nKb;
+  const int iA = c < 0 ? -c : 0;                        // first row with a non-negative length
+  int iB = nKb - c;                                     // first row at full length
+  iB = iB < iA ? iA : iB;
+  const int e1 = qt < iB ? qt : iB;
+  const int64_t n1 = e1 > iA ? e1 - iA : 0;
+  const int64_t n2 = qt > iB ? qt - iB : 0;
+  return n1 * (iA + c) + n1 * (n1 - 1) / 2 + n2 * nKb;
+}
 int bwd_dq_rows_per_block();
 int bwd_dkdv_keys_per_block(bool wide);
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);

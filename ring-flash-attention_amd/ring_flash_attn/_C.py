@@ -10,12 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RFA_LIB_PATH: A/B tooling only (tools/ab_variants.py builds tuning variants of the same library)
 LIB_PATH = os.environ.get("RFA_LIB_PATH") or os.path.join(_HERE, "librfa_hip.so")
 
-RFA_ABI_VERSION = 3
+RFA_ABI_VERSION = 4
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
 BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
 BWD_KV_OVERWRITE = 16     # dk_acc / dv_acc are overwritten (dq_acc still follows acc_init)
+DKDV_AUTO, DKDV_128, DKDV_256 = 0, 1, 2
 
 
 class Strides(C.Structure):
@@ -78,6 +79,7 @@ class BwdArgs(C.Structure):
         ("phases", C.c_int32),
         ("ds_scratch", C.c_void_p),
         ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
+        ("dkdv_form", C.c_int32), ("dkdv_nsplit", C.c_int32),
     ]
 
 
@@ -112,6 +114,7 @@ SYMBOLS = {
     "rfa_bwd_preprocess": (C.c_int, [C.POINTER(BwdPreArgs), C.c_void_p]),
     "rfa_bwd_workspace_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
     "rfa_bwd_ds_scratch_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
+    "rfa_bwd_plan": (C.c_int, [C.POINTER(BwdArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rfa_bwd": (C.c_int, [C.POINTER(BwdArgs), C.c_void_p]),
     "rfa_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),
     "rfa_sum_slots": (C.c_int, [C.POINTER(SumSlotsArgs), C.c_void_p]),

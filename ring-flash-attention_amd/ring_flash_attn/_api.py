@@ -13,7 +13,6 @@ inputs are the caller's LOCAL shard.
 import torch
 
 from ._common import _prep_qkv, _as_cu
-from .utils import backward_expected, grad_mode_at_call
 
 
 def _opaque(fn):
@@ -46,12 +45,18 @@ def _compilable(fn, lower):
 
     eager = _opaque(fn)
 
+    import inspect
+
+    sig = inspect.signature(fn)
+
     @functools.wraps(fn)
     def public(*args, **kwargs):
-        if torch.compiler.is_compiling() and _single_rank(kwargs.get("group", None)):
-            return lower(*args, **kwargs)
-        with grad_mode_at_call():
-            return eager(*args, **kwargs)
+        if torch.compiler.is_compiling():
+            # `group` may be passed positionally: resolve it the way the call itself would
+            group = sig.bind(*args, **kwargs).arguments.get("group", None)
+            if _single_rank(group):
+                return lower(*args, **kwargs)
+        return eager(*args, **kwargs)
 
     return public
 
@@ -80,6 +85,24 @@ def window_ok_for(group) -> bool:
     return group_rank_world(group)[1] == 1
 
 
+def _keep_list(ctx, forward_impl):
+    """Schedules that can hand buffers from their forward to their backward (`forward_impl.keeps_for_backward`: the
+    zigzag gather form keeps the K/V it gathered) get a list to append tensors to — only when an input needs a
+    gradient.  The tensors are stored with ctx.save_for_backward, i.e. they are owned by the autograd graph: freed with
+    it, never kept for torch.no_grad() calls (no graph), discarded and re-made under activation checkpointing, visible
+    to saved-tensor hooks (offloading) — there is no process-global hand-off."""
+    if getattr(forward_impl, "keeps_for_backward", False) and any(ctx.needs_input_grad[:3]):
+        keep = []
+        return keep, {"keep": keep}
+    return None, {}
+
+
+def _split_kept(ctx, more):
+    n = getattr(ctx, "n_lead_t", len(more))
+    tensors_lead, kept = more[:n], more[n:]
+    return tensors_lead, ({"kept": tuple(kept)} if kept else {})
+
+
 def make_autograd_function(name, forward_impl, backward_impl, n_lead):
     """n_lead: number of non-tensor positional arguments between (q,k,v) and the common tail
     (0 for the batch API, 2 = (cu_seqlens, max_seqlen) for varlen)."""
@@ -99,12 +122,13 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 cu = _as_cu(lead[0], q.device)
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
-            with backward_expected(any(ctx.needs_input_grad[:3])):
-                out, softmax_lse = forward_impl(
-                    group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
-                    window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
-                )
-            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
+            keep, extra = _keep_list(ctx, forward_impl)
+            out, softmax_lse = forward_impl(
+                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
+            )
+            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
+            ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale
             ctx.causal = causal
@@ -115,11 +139,12 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
 
         @staticmethod
         def backward(ctx, dout, *args):
-            q, k, v, out, softmax_lse, *tensors_lead = ctx.saved_tensors
+            q, k, v, out, softmax_lse, *more = ctx.saved_tensors
+            tensors_lead, extra = _split_kept(ctx, more)
             dq, dk, dv = backward_impl(
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
                 softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
-                window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic,
+                window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic, **extra,
             )
             return (dq, dk, dv) + (None,) * (n_lead + 8)
 
@@ -154,12 +179,13 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 cu = _as_cu(lead[0], q.device)
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
-            with backward_expected(any(ctx.needs_input_grad[:3])):
-                out, softmax_lse = forward_impl(
-                    group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
-                    window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
-                )
-            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead)
+            keep, extra = _keep_list(ctx, forward_impl)
+            out, softmax_lse = forward_impl(
+                group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+                window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
+            )
+            ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
+            ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale
             ctx.causal = causal
@@ -171,7 +197,8 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
 
         @staticmethod
         def backward(ctx, dout, *args):
-            q, k, v, out, softmax_lse, *tensors_lead = ctx.saved_tensors
+            q, k, v, out, softmax_lse, *more = ctx.saved_tensors
+            tensors_lead, extra = _split_kept(ctx, more)
             shape, dtype, device = ctx.packed_meta
             dpacked = torch.empty(shape, dtype=dtype, device=device)
             views = [dpacked.select(pack_dim, i) for i in range(n_packed)]
@@ -183,7 +210,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
                 softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
                 window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic,
-                out_grads=out_grads,
+                out_grads=out_grads, **extra,
             )
             got = (dq, dk, dv)[3 - n_packed:]
             for view, g in zip(views, got):

@@ -84,6 +84,8 @@ def _attn_bwd_fake(dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scal
             torch.empty(v.shape, dtype=v.dtype, device=v.device))
 
 
+# (`deterministic` is not threaded through: the kernels are always deterministic — no atomics — so the flag the eager
+#  path records has no effect on the result either)
 def _setup_context(ctx, inputs, output):
     q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, window_left, window_right = inputs
     ctx.window = (window_left, window_right)
@@ -106,9 +108,21 @@ torch.library.register_autograd("rfa::attn_fwd", _backward, setup_context=_setup
 
 def single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs,
                             window_size=(-1, -1)):
-    """what every schedule of this package reduces to on a single-rank group, as traceable operators"""
+    """what every schedule of this package reduces to on a single-rank group, as traceable operators.  Inputs are
+    normalised exactly as the eager entry points do (_common._prep_qkv / _as_cu): unit head_dim stride, int32
+    cu_seqlens on the compute device."""
     if softmax_scale is None:
         softmax_scale = q.shape[-1] ** (-0.5)
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    if k.stride(-1) != 1:
+        k = k.contiguous()
+    if v.stride(-1) != 1:
+        v = v.contiguous()
+    if cu_seqlens is not None:
+        if not torch.is_tensor(cu_seqlens):
+            cu_seqlens = torch.tensor(cu_seqlens, dtype=torch.int32)
+        cu_seqlens = cu_seqlens.to(device=q.device, dtype=torch.int32).contiguous()
     out, lse = torch.ops.rfa.attn_fwd(q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal),
                                       int(window_size[0]), int(window_size[1]))
     return (out, lse, None) if return_attn_probs else out

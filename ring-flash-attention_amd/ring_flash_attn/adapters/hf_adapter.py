@@ -71,8 +71,9 @@ def _ring_attention(query_states, key_states, value_states, *, dropout, softmax_
                     softcap=None, deterministic=None, sliding_window=None):
     """(1,S,H,D) local q/k/v -> (1,S,H,D).  Same guards as reference hf_adapter.py:137-147."""
     # reference hf_adapter.py:121-128: a configured sliding window that is shorter than the (local) key length
-    # is forwarded as window_size=(w, w).  The kernels have no window support, so this raises
-    # NotImplementedError in llama3_flash_attn_varlen_func instead of silently attending to everything.
+    # is forwarded as window_size=(w, w); llama3_flash_attn_varlen_func applies it in the kernels (flash_attn
+    # window semantics; with `causal` the right bound is 0), on any world size: it gathers K/V, so one kernel call
+    # sees every key a query may attend to.
     window_size = (-1, -1)
     if sliding_window is not None and key_states.shape[1] > sliding_window:
         window_size = (sliding_window, sliding_window)

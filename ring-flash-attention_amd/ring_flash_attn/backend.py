@@ -185,18 +185,25 @@ class HipBackend:
             a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         a.phases = phases
-        # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
-        # recomputing S and dP, when the call is eligible (D == 128, whole sequences, dense or packed) and the scratch stays below
-        # RFA_DS_SPILL_MAX_BYTES; RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
-        # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
         reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
+        # dK/dV launch plan: part of the call (ABI 4).  The tuning / test overrides RFA_DKDV_WIDE, RFA_DKDV_NSPLIT are
+        # read HERE, once per backward: a REDUCE call reuses the plan its COMPUTE call ran with (it travels with the
+        # `partials` token), so the two phases cannot disagree whatever happens to the environment in between.
+        if reduce_only and partials is not None and hasattr(partials, "_rfa_plan"):
+            a.dkdv_form, a.dkdv_nsplit = partials._rfa_plan
+        else:
+            a.dkdv_form, a.dkdv_nsplit = _plan_overrides()
+        # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
+        # recomputing S and dP, when the call is eligible (D == 128, whole sequences, dense or packed) and the scratch
+        # fits (bwd_ds_scratch below); RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
+        # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
         if ds_scratch is None and not reduce_only and _spill_enabled():
             ds_scratch = self.bwd_ds_scratch(a, q.device)
         if ds_scratch is not None and not reduce_only:
             a.ds_scratch = ds_scratch.data_ptr()
         nbytes = self.lib.rfa_bwd_workspace_bytes(C.byref(a))
         ws = None
-        if (phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE):
+        if reduce_only:
             if partials is None:
                 raise RuntimeError("rfa_bwd: a BWD_REDUCE call needs the `partials` buffer its BWD_COMPUTE call returned")
             if partials.device != q.device or partials.numel() < nbytes:
@@ -204,17 +211,45 @@ class HipBackend:
             ws = partials
         elif nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            ws._rfa_plan = (a.dkdv_form, a.dkdv_nsplit)
         if ws is not None:
             a.workspace = ws.data_ptr()
         _C.check(self.lib.rfa_bwd(C.byref(a), _stream(q)), "rfa_bwd")
         return ws if (phases & _C.BWD_COMPUTE) else None
 
+    def bwd_plan(self, a):
+        """(form, nsplit, five_gemm) the call described by `a` (a filled BwdArgs) will run"""
+        form, ns, five = C.c_int32(), C.c_int32(), C.c_int32()
+        _C.check(self.lib.rfa_bwd_plan(C.byref(a), C.byref(form), C.byref(ns), C.byref(five)), "rfa_bwd_plan")
+        return form.value, ns.value, five.value
+
     def bwd_ds_scratch(self, a, device):
-        """scratch tensor for the dS spill of the call described by `a` (a filled BwdArgs), or None"""
+        """Scratch tensor for the dS spill of the call described by `a` (a filled BwdArgs), or None: the call then
+        runs the 7-GEMM form.  The scratch is transient (one backward) but large — B*H*S^2 bytes for a dense causal
+        call, 2.2 GB at the headline shape, 8.6 GB at S = 16384 — so it is only taken when it stays below
+        RFA_DS_SPILL_MAX_BYTES (default 16 GiB) AND below RFA_DS_SPILL_MAX_FRAC (default 0.5) of the memory that is
+        free right now (device free + torch's cached-but-unused pool), and an allocation failure falls back to the
+        7-GEMM form instead of failing a backward that would have fitted without the spill.  Both refusals are
+        logged once per process."""
         sbytes = self.lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
-        if 0 < sbytes <= _spill_limit():
+        if sbytes <= 0:
+            return None
+        limit = _spill_limit()
+        if sbytes <= limit and device.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(device)
+            st = torch.cuda.memory_stats(device)
+            cached = st.get("reserved_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)
+            limit = min(limit, int(_spill_frac() * (free + cached)))
+        if sbytes > limit:
+            _log_once("spill-limit", f"ring_flash_attn: dS spill of {sbytes / 2**30:.2f} GiB refused (limit "
+                                     f"{limit / 2**30:.2f} GiB): this backward runs the 7-GEMM form")
+            return None
+        try:
             return torch.empty(sbytes, dtype=torch.uint8, device=device)
-        return None
+        except torch.OutOfMemoryError:
+            _log_once("spill-oom", f"ring_flash_attn: dS spill of {sbytes / 2**30:.2f} GiB could not be allocated: "
+                                   "this backward runs the 7-GEMM form")
+            return None
 
     # ------------------------------------------------------------------ side kernels
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):
@@ -295,6 +330,35 @@ def _spill_enabled() -> bool:
 def _spill_limit() -> int:
     import os
     return int(os.environ.get("RFA_DS_SPILL_MAX_BYTES", str(16 << 30)))
+
+
+def _spill_frac() -> float:
+    import os
+    return float(os.environ.get("RFA_DS_SPILL_MAX_FRAC", "0.5"))
+
+
+def _plan_overrides():
+    """(dkdv_form, dkdv_nsplit) from the tuning / test switches RFA_DKDV_WIDE=0|1 and RFA_DKDV_NSPLIT=n (n > 0 also
+    forces the 256-key form); (AUTO, 0) when unset"""
+    import os
+    wide, ns = os.environ.get("RFA_DKDV_WIDE", ""), os.environ.get("RFA_DKDV_NSPLIT", "")
+    nsplit = int(ns) if ns.strip() else 0
+    form = _C.DKDV_AUTO
+    if wide.strip() == "0":
+        form = _C.DKDV_128
+    elif nsplit > 0:
+        form = _C.DKDV_256
+    return form, max(nsplit, 0)
+
+
+_LOGGED = set()
+
+
+def _log_once(key, msg):
+    if key not in _LOGGED:
+        _LOGGED.add(key)
+        import sys
+        sys.stderr.write(msg + "\n")
 
 
 _backend = None

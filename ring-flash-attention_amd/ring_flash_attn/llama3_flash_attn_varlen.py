@@ -47,56 +47,47 @@ def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world
 
 
 def llama3_flash_attn_prepare_cu_seqlens(cu_seqlens: torch.Tensor, causal: bool, rank: int, world_size: int):
-    """
-    Args:
-        cu_seqlens: torch.Tensor, the cu_seqlens of all the sequences across the ring process group.
+    """Per-rank view of a packed token stream cut into `world_size` equal slices (integer work only; same results as
+    /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:10-60, checked bit for bit against 96 vectors the
+    reference produced: tests/test_abi.py::test_prepare_cu_seqlens_golden).
 
-    Returns:
-        cu_seqlens_q: torch.Tensor, the cu_seqlens of the q slice for this rank.
-        cu_seqlens_k: torch.Tensor, the cu_seqlens of the k slice that the local q need. Note
-            that this may be longer than `total_seq_len // world_size`.
-        local_k_slice: slice, the slice of the k that the local q need. Note
-            that this may be longer than `total_seq_len // world_size`.
-    """
-    cu = [int(x) for x in cu_seqlens.tolist()]      # one device->host copy
-    total_length = cu[-1]
-    assert total_length % world_size == 0
-    length_per_rank = total_length // world_size
-    lo, hi = rank * length_per_rank, (rank + 1) * length_per_rank
+    cu_seqlens are the GLOBAL cumulative sequence lengths.  Returns
+        cu_seqlens_q   boundaries of the sequence pieces inside this rank's query slice (starts at 0, ends at T/W)
+        cu_seqlens_k   boundaries of the keys those pieces attend to, relative to the first needed key; with
+                       `causal` the last piece's keys stop where the local queries stop, otherwise at the end of
+                       its sequence — so the key range may be longer than T/W on both sides
+        max_seqlen_q, max_seqlen_k
+        local_k_slice  the slice of the GATHERED key rows that range covers
+    The work is done on one host copy of cu_seqlens (a single device-to-host transfer)."""
+    cu = [int(x) for x in cu_seqlens.tolist()]
+    total = cu[-1]
+    assert total % world_size == 0
+    per_rank = total // world_size
+    lo, hi = rank * per_rank, (rank + 1) * per_rank
 
-    def searchsorted(val):                           # torch.searchsorted(..., right=False)
+    def first_at_least(val):                         # index of the first boundary >= val
         i = 0
         while i < len(cu) and cu[i] < val:
             i += 1
         return i
 
-    left = searchsorted(lo)
-    right = searchsorted(hi)
-    # after this, cu[left:right + 1] contains all the sequences that touch this rank
-    if cu[left] != lo:
+    left, right = first_at_least(lo), first_at_least(hi)
+    if cu[left] != lo:                               # the slice starts inside a sequence: include its start
         left -= 1
+    touched = cu[left:right + 1]                     # boundaries of every sequence with a token in [lo, hi)
 
-    cu_q = [c - lo for c in cu[left:right + 1]]
-    cu_q[0] = 0
-    cu_q[-1] = length_per_rank
+    cu_q = [c - lo for c in touched]
+    cu_q[0], cu_q[-1] = 0, per_rank                  # clip the first / last piece to the slice
 
-    cu_k = list(cu[left:right + 1])
-    if causal:
-        # the last k sequence ends where the last local q sequence ends
-        slice_right = hi
-        cu_k[-1] = slice_right
-    else:
-        # the last k is the full sequence
-        slice_right = cu[right]
-    slice_left = cu[left]
-    cu_k = [c - slice_left for c in cu_k]
+    k_first = touched[0]
+    k_last = hi if causal else cu[right]             # causal: nothing beyond the last local query is visible
+    cu_k = [c - k_first for c in touched[:-1]] + [k_last - k_first]
 
     max_seqlen_q = max(b - a for a, b in zip(cu_q[:-1], cu_q[1:]))
     max_seqlen_k = max(b - a for a, b in zip(cu_k[:-1], cu_k[1:]))
-    local_k_slice = slice(slice_left, slice_right)
     cu_seqlens_q = torch.tensor(cu_q, dtype=cu_seqlens.dtype, device=cu_seqlens.device)
     cu_seqlens_k = torch.tensor(cu_k, dtype=cu_seqlens.dtype, device=cu_seqlens.device)
-    return cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, local_k_slice
+    return cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, slice(k_first, k_last)
 
 
 def llama3_flash_attn_varlen_forward(
@@ -305,8 +296,6 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
 
 
 def _make_llama3_api():
-    lead = "cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice"
-
     def func(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
              dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
              deterministic=False, return_attn_probs=False, group=None):
@@ -314,15 +303,22 @@ def _make_llama3_api():
             q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
             dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic, return_attn_probs, group)
 
-    def kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
-                      local_k_slice, **kw):
-        return func(q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-                    heads_k_stride, local_k_slice, **kw)
+    # (same positional tails as the reference wrappers, llama3_flash_attn_varlen.py:390-445)
+    def kvpacked_func(q, kv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+                      dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+                      deterministic=False, return_attn_probs=False, group=None):
+        return Llama3FlashAttnVarlenFunc.apply(
+            q, kv[:, 0], kv[:, 1], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+            local_k_slice, dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic,
+            return_attn_probs, group)
 
-    def qkvpacked_func(qkv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
-                       local_k_slice, **kw):
-        return func(qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-                    heads_k_stride, local_k_slice, **kw)
+    def qkvpacked_func(qkv, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+                       dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+                       deterministic=False, return_attn_probs=False, group=None):
+        return Llama3FlashAttnVarlenFunc.apply(
+            qkv[:, 0], qkv[:, 1], qkv[:, 2], cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+            local_k_slice, dropout_p, softmax_scale, causal, window_size, alibi_slopes, deterministic,
+            return_attn_probs, group)
 
     func.__name__ = func.__qualname__ = "llama3_flash_attn_varlen_func"
     kvpacked_func.__name__ = kvpacked_func.__qualname__ = "llama3_flash_attn_varlen_kvpacked_func"

@@ -116,43 +116,6 @@ def single_rank(world_size: int) -> bool:
     return world_size == 1 and os.environ.get("RFA_TEST_FORCE_STEPS", "0") != "1"
 
 
-# Set by the autograd Functions around a schedule's forward: will a backward follow (an input needs a gradient)?
-# The zigzag gather form keeps its gathered K/V for that backward only then.
-_BACKWARD_EXPECTED = False
-
-
-class backward_expected:
-    def __init__(self, flag: bool):
-        self.flag = bool(flag)
-
-    def __enter__(self):
-        global _BACKWARD_EXPECTED
-        self.prev, _BACKWARD_EXPECTED = _BACKWARD_EXPECTED, self.flag
-
-    def __exit__(self, *exc):
-        global _BACKWARD_EXPECTED
-        _BACKWARD_EXPECTED = self.prev
-
-
-def is_backward_expected() -> bool:
-    return _BACKWARD_EXPECTED and _GRAD_MODE_AT_CALL
-
-
-# grad mode at the moment the PUBLIC function was called (inside autograd.Function.forward it is always off, and
-# needs_input_grad only reflects the tensors' requires_grad flags): torch.no_grad() inference keeps nothing
-_GRAD_MODE_AT_CALL = True
-
-
-class grad_mode_at_call:
-    def __enter__(self):
-        global _GRAD_MODE_AT_CALL
-        self.prev, _GRAD_MODE_AT_CALL = _GRAD_MODE_AT_CALL, torch.is_grad_enabled()
-
-    def __exit__(self, *exc):
-        global _GRAD_MODE_AT_CALL
-        _GRAD_MODE_AT_CALL = self.prev
-
-
 def group_rank_world(process_group):
     """(rank, world_size) of the group — the one place the schedules ask for it"""
     if _LOOPBACK is not None:

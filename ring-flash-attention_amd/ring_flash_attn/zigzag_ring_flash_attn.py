@@ -46,8 +46,7 @@ import torch
 
 from . import _C
 from .backend import get_backend
-from .utils import (AllGatherComm, RingComm, all_to_all_async, is_backward_expected, reduce_scatter_async,
-                    single_rank)
+from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 from ._common import packed_pair
 
@@ -75,59 +74,47 @@ def exchange_mode(k: torch.Tensor, world: int) -> str:
 
 
 # ---------------------------------------------------------------------------------------------
-# The K/V gathered by a forward are kept for its backward (W x (K, V) io dtype per pending backward: 0.27 GB at
-# W = 8, Hk = 8, S = 8192/rank) instead of being gathered a second time.  With the K/V already present the backward
-# can run its REMOTE steps first and the local causal block last, so that the one all-to-all of the dK/dV
-# contributions is posted before the local block and runs beside it — no exchange is left on the critical path
-# of the backward.  Entries hold a reference to the k / v they were gathered from (so their addresses cannot be
-# recycled while the entry lives) and are matched on address, shape, dtype and tensor version; a miss (evicted,
-# RFA_ZIGZAG_KV_CACHE=0, checkpointing that dropped it) gathers again and keeps the local-block-first order.
-_KV_CACHE = {}          # insertion ordered: oldest first
-
-
-def _kv_cache_limit() -> int:
-    if os.environ.get("RFA_ZIGZAG_KV_CACHE", "1") == "0":
+# The K/V gathered by a forward are kept for its backward (W x (K, V) io dtype: 0.27 GB at W = 8, Hk = 8,
+# S = 8192/rank) instead of being gathered a second time.  With the K/V already present the backward can run its
+# REMOTE steps first and the local causal block last, so that the one all-to-all of the dK/dV contributions is
+# posted before the local block and runs beside it — no exchange is left on the critical path of the backward.
+# The buffers are SAVED TENSORS of the autograd node (_api._keep_list): owned by the graph, freed with it, dropped
+# and re-made under activation checkpointing, never created for a forward without a backward.  A forward whose
+# gathered K/V exceed RFA_ZIGZAG_KV_KEEP_BYTES (default 4 GiB per call; RFA_ZIGZAG_KV_KEEP=0: never) keeps
+# nothing: its backward gathers again and keeps the local-block-first order.
+def _kv_keep_limit() -> int:
+    if os.environ.get("RFA_ZIGZAG_KV_KEEP", os.environ.get("RFA_ZIGZAG_KV_CACHE", "1")) == "0":
         return 0
-    return int(os.environ.get("RFA_ZIGZAG_KV_CACHE_BYTES", str(2 << 30)))
+    return int(os.environ.get("RFA_ZIGZAG_KV_KEEP_BYTES", str(4 << 30)))
 
 
-def _kv_key(group, k, v, world, rank):
-    return (id(group), k.data_ptr(), v.data_ptr(), tuple(k.shape), tuple(k.stride()), k.dtype, k._version,
-            v._version, world, rank)
-
-
-def _kv_cache_put(group, k, v, world, rank, k_all, v_all):
-    limit = _kv_cache_limit()
-    nbytes = 2 * world * k.numel() * k.element_size()
-    if nbytes > limit:
-        return
-    _KV_CACHE[_kv_key(group, k, v, world, rank)] = (k, v, k_all, v_all, nbytes)
-    while sum(e[4] for e in _KV_CACHE.values()) > limit:
-        _KV_CACHE.pop(next(iter(_KV_CACHE)))
-
-
-def _kv_cache_take(group, k, v, world, rank):
-    e = _KV_CACHE.pop(_kv_key(group, k, v, world, rank), None)
-    return None if e is None else (e[2], e[3])
+def _kv_views(bufs, k, world):
+    """(k_all, v_all) views — indexed by source rank — of the gathered base buffers `bufs`"""
+    if len(bufs) == 1:                                   # packed kv travelled as one buffer
+        kv_all = bufs[0].view((world, k.shape[0], k.shape[1], 2) + tuple(k.shape[2:]))
+        return kv_all.select(-3, 0), kv_all.select(-3, 1)
+    return bufs[0].view((world,) + tuple(k.shape)), bufs[1].view((world,) + tuple(k.shape))
 
 
 def _gather_kv(comm_group, k, v, world):
-    """posts the all-gather of k and v; returns (handle, k_all, v_all) with *_all[(src rank)] views.  k and v that are
-    the two halves of one packed kv tensor (kvpacked entry points) travel as that one buffer: one collective of twice
-    the size instead of two, no contiguous copies; the per-rank K / V are then strided views of the gathered buffer."""
+    """posts the all-gather of k and v; returns (handle, bufs, k_all, v_all): `bufs` the gathered base buffers,
+    *_all[(src rank)] views of them.  k and v that are the two halves of one packed kv tensor (kvpacked entry points)
+    travel as that one buffer: one collective of twice the size instead of two, no contiguous copies; the per-rank
+    K / V are then strided views of the gathered buffer."""
     gather = AllGatherComm(comm_group)
     kv = packed_pair(k, v)
     if kv is not None:
         kv_cat = torch.empty((world * kv.shape[0],) + tuple(kv.shape[1:]), dtype=kv.dtype, device=kv.device)
         gather.all_gather(kv_cat, kv)
-        kv_all = kv_cat.view((world,) + tuple(kv.shape))
-        return gather, kv_all.select(-3, 0), kv_all.select(-3, 1)
-    # (world*B, ...) for the collective (the concatenated form every backend accepts), (world, B, ...) to index
-    k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
-    v_cat = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-    gather.all_gather(k_cat, k.contiguous())
-    gather.all_gather(v_cat, v.contiguous())
-    return gather, k_cat.view((world,) + tuple(k.shape)), v_cat.view((world,) + tuple(v.shape))
+        bufs = [kv_cat]
+    else:
+        # (world*B, ...) for the collective (the concatenated form every backend accepts), (world, B, ...) to index
+        k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
+        v_cat = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        gather.all_gather(k_cat, k.contiguous())
+        gather.all_gather(v_cat, v.contiguous())
+        bufs = [k_cat, v_cat]
+    return (gather, bufs) + _kv_views(bufs, k, world)
 
 
 def zigzag_ring_flash_attn_forward(
@@ -141,7 +128,10 @@ def zigzag_ring_flash_attn_forward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    keep=None,
 ):
+    """keep: a list (or None) the gather form appends its gathered K/V buffers to — the autograd Function saves them
+    for the backward (`kept=`)"""
     assert causal == True, "zigzag ring is meaningless for causal=False"
     be = get_backend()
     comm = RingComm(process_group)
@@ -158,12 +148,12 @@ def zigzag_ring_flash_attn_forward(
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
 
     if exchange_mode(k, comm.world_size) == "gather":
-        gather, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
+        gather, bufs, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
         gather.wait()
-        if is_backward_expected():
-            _kv_cache_put(process_group, k, v, comm.world_size, comm.rank, k_all, v_all)
+        if keep is not None and sum(b_.numel() * b_.element_size() for b_ in bufs) <= _kv_keep_limit():
+            keep.extend(bufs)
         for step in range(1, comm.world_size):
             src = (comm.rank - step) % comm.world_size
             ks, vs = k_all[src], v_all[src]
@@ -214,7 +204,9 @@ def zigzag_ring_flash_attn_backward(
     alibi_slopes=None,
     deterministic=False,
     out_grads=None,
+    kept=None,
 ):
+    """kept: the gathered K/V buffers the forward handed over (`keep=`), or None"""
     assert causal == True, "zigzag ring is meaningless for causal=False"
     be = get_backend()
     kv_comm = RingComm(process_group)
@@ -240,11 +232,10 @@ def zigzag_ring_flash_attn_backward(
     if exchange_mode(k, kv_comm.world_size) == "gather":
         W, rank = kv_comm.world_size, kv_comm.rank
         wire32 = _wire_fp32()
-        kept = _kv_cache_take(process_group, k, v, W, rank)
-        if kept is not None:
-            gather, (k_all, v_all) = None, kept
+        if kept:
+            gather, (k_all, v_all) = None, _kv_views(kept, k, W)
         else:
-            gather, k_all, v_all = _gather_kv(process_group, k, v, W)
+            gather, _, k_all, v_all = _gather_kv(process_group, k, v, W)
         # K/V of every rank are here already: remote steps first, local block beside the all-to-all (the fp32
         # reduce-scatter wire keeps the local-first order)
         local_last = gather is None and not wire32
@@ -316,8 +307,10 @@ def zigzag_ring_flash_attn_backward(
             # carried nothing)
             own = [torch.empty((c.shape[0] // W,) + tuple(c.shape[1:]), dtype=wdt, device=q.device) for c in cats]
             own_kv = (dict(dk=own[0].select(-3, 0), dv=own[0].select(-3, 1)) if packed else dict(dk=own[0], dv=own[1]))
+            # (a one-rank group on the forced multi-step path has no remote step: the local block is then the first —
+            #  and only — kernel that touches dq)
             be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-                   dq_acc=dq, acc_init=False, deterministic=deterministic, **own_kv)
+                   dq_acc=dq, acc_init=W == 1, deterministic=deterministic, **own_kv)
         dq_out = be.cast(dq, q.dtype)                                      # runs beside the exchange
         for w_ in works:
             w_.wait()
@@ -388,6 +381,8 @@ def zigzag_ring_flash_attn_backward(
 
     return be.cast(dq, q.dtype), be.cast(next_dk, q.dtype), be.cast(next_dv, q.dtype)
 
+
+zigzag_ring_flash_attn_forward.keeps_for_backward = True
 
 ZigZagRingFlashAttnFunc = make_autograd_function(
     "ZigZagRingFlashAttnFunc", zigzag_ring_flash_attn_forward, zigzag_ring_flash_attn_backward, 0)

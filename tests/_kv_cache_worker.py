@@ -22,16 +22,38 @@ def run(rank, W, port, ret):
     torch.manual_seed(rank)
     q = torch.randn(1, 64, 2, 32).bfloat16().requires_grad_(True)
     kv = torch.randn(1, 64, 2, 2, 32).bfloat16().requires_grad_(True)
+    import gc
+    import weakref
+
+    def n_saved(out):
+        return None if out.grad_fn is None else len(out.grad_fn.saved_tensors)
+
     counts = []
     out = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
-    counts.append(len(Z._KV_CACHE))                 # kept for the backward
+    counts.append(n_saved(out))                     # q, k, v, out, lse + the ONE gathered (packed) kv buffer
+    gathered = out.grad_fn.saved_tensors[5]
+    assert gathered.shape[0] == W * kv.shape[0]
+    ref = weakref.ref(gathered)
+    del gathered
     out.sum().backward()
-    counts.append(len(Z._KV_CACHE))                 # consumed
+    g_keep = kv.grad.clone()
+    del out
+    gc.collect()
+    counts.append(ref() is None)                    # freed with the graph: nothing lives on after the backward
     with torch.no_grad():
-        R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
-    counts.append(len(Z._KV_CACHE))                 # inference keeps nothing
-    R.zigzag_ring_flash_attn_kvpacked_func(q.detach(), kv.detach(), causal=True)
-    counts.append(len(Z._KV_CACHE))                 # no input needs a gradient
+        o2 = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+    counts.append(n_saved(o2))                      # inference: no graph, nothing kept
+    o3 = R.zigzag_ring_flash_attn_kvpacked_func(q.detach(), kv.detach(), causal=True)
+    counts.append(n_saved(o3))                      # no input needs a gradient
+    # over the per-call limit (or RFA_ZIGZAG_KV_KEEP=0): nothing is kept, the backward gathers again, same gradients
+    for env, val in (("RFA_ZIGZAG_KV_KEEP_BYTES", "16"), ("RFA_ZIGZAG_KV_KEEP", "0")):
+        os.environ[env] = val
+        kv.grad = None
+        o4 = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+        counts.append(n_saved(o4))
+        o4.sum().backward()
+        counts.append(bool(torch.equal(kv.grad, g_keep)) or float((kv.grad.float() - g_keep.float()).abs().max()) < 2e-2)
+        del os.environ[env]
     ret[rank] = counts
     dist.barrier()
     dist.destroy_process_group()

@@ -68,6 +68,30 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
             backend.set_backend(OracleBackend())
             tol = TOL_ORACLE
         errs = []
+        compiled = os.environ.get("RFA_TEST_COMPILE") == "1"
+        if compiled:
+            # the reference runs its tests a second time with the function under torch.compile at the full world
+            # size (test/test.sh:23-25, test/test_zigzag_ring_flash_attn_func.py:105-108).  With several ranks the
+            # schedules are opaque to dynamo (torch.compiler.disable: kernels interleaved with torch.distributed
+            # traffic): a compiled CALLER is traced up to the call, the schedule runs eagerly, tracing resumes
+            # behind it.  Every public function is replaced by such a compiled caller (with traced tensor work on
+            # both sides of the call) and must give the same results as the plain call, bit for bit.
+            import types
+            from torch import _dynamo as dynamo
+
+            dynamo.reset()
+            eager_R, R = R, types.SimpleNamespace()
+
+            def compiled_caller(fn):
+                def caller(*a, **kw_):
+                    a = tuple((t * 1 if torch.is_tensor(t) and t.is_floating_point() else t) for t in a)
+                    res = fn(*a, **kw_)
+                    return tuple((t + 0 if torch.is_tensor(t) else t) for t in res) if isinstance(res, tuple) else res + 0
+                return torch.compile(caller, backend="aot_eager")
+
+            for name in dir(eager_R):
+                obj = getattr(eager_R, name)
+                setattr(R, name, compiled_caller(obj) if name.endswith("_func") else obj)
         for n in names:
             c = MG.CASES[n]
             (q, k, v, do), extra = MG.shard(c, rank)
@@ -105,6 +129,22 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                 out, lse, _ = R.llama3_flash_attn_varlen_func(q, k, v, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=c["stride"],
                                                               local_k_slice=sl, causal=True, **kw)
             out.backward(do)
+            if compiled and kind in ("zigzag", "ring", "zigzag_varlen", "llama3"):
+                # same call without torch.compile: identical bits
+                efn = {"zigzag": lambda: eager_R.zigzag_ring_flash_attn_func(qe, ke, ve, causal=True, **kw),
+                       "ring": lambda: eager_R.ring_flash_attn_func(qe, ke, ve, causal=c["causal"], **kw),
+                       "zigzag_varlen": lambda: eager_R.zigzag_ring_flash_attn_varlen_func(
+                           qe, ke, ve, extra["cu_local"].to(dev), extra["max_local"], causal=True, **kw),
+                       "llama3": lambda: eager_R.llama3_flash_attn_varlen_func(
+                           qe, ke, ve, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=c["stride"], local_k_slice=sl,
+                           causal=True, **kw)}[kind]
+                qe, ke, ve = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
+                oe, le, _ = efn()
+                oe.backward(do)
+                for nm, a_, b_ in (("out", out, oe), ("lse", lse, le), ("dq", q.grad, qe.grad), ("dk", k.grad, ke.grad),
+                                   ("dv", v.grad, ve.grad)):
+                    if not torch.equal(a_.detach(), b_.detach()):
+                        errs.append(f"{n}[r{rank}].{nm}: compiled caller differs from the eager call")
 
             def pick(t):
                 # sampled cases store every `sample`-th row (+ first / last 8) of the row-indexed tensors

@@ -124,9 +124,12 @@ def test_public_api_surface():
         for suffix, first in (("func", ["q", "k", "v"]), ("kvpacked_func", ["q", "kv"]), ("qkvpacked_func", ["qkv"])):
             fn = getattr(r, f"{prefix}_{suffix}")
             assert list(inspect.signature(fn).parameters) == first + lead + tail
-    sig = list(inspect.signature(r.llama3_flash_attn_varlen_func).parameters)
-    assert sig == ["q", "k", "v", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "heads_k_stride",
-                   "local_k_slice"] + tail
+    l3 = ["cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "heads_k_stride", "local_k_slice"]
+    # (reference llama3_flash_attn_varlen.py:390-504: the packed wrappers take the same positional tail)
+    for suffix, first in (("func", ["q", "k", "v"]), ("kvpacked_func", ["q", "kv"]), ("qkvpacked_func", ["qkv"])):
+        sig = inspect.signature(getattr(r, f"llama3_flash_attn_varlen_{suffix}"))
+        assert list(sig.parameters) == first + l3 + tail
+        assert [sig.parameters[n].default for n in tail] == [0.0, None, False, (-1, -1), None, False, False, None]
     assert list(inspect.signature(r.llama3_flash_attn_prepare_cu_seqlens).parameters) == ["cu_seqlens", "causal", "rank", "world_size"]
     assert callable(r.substitute_hf_flash_attn) and callable(r.update_ring_flash_attn_params)
     # beyond the reference (its README TODO): zigzag_llama3 takes the GLOBAL cu_seqlens
@@ -191,17 +194,18 @@ def test_flash_attn_shim_surface(built):
         F._flash_attn_forward(q, q, q, 0.0, 0.125, True, softcap=30.0)
 
 
-def test_backward_plan_is_a_function_of_the_shapes(built, monkeypatch):
-    """rfa_bwd_workspace_bytes / rfa_bwd_ds_scratch_bytes (host code): which dK/dV kernel form a call runs and
-    how much scratch it asks for — the numbers DESIGN.md quotes for the headline, and the rule that a
-    BWD_COMPUTE / BWD_REDUCE pair and the sizing call agree because only shapes enter."""
+def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
+    """rfa_bwd_plan / rfa_bwd_workspace_bytes / rfa_bwd_ds_scratch_bytes (host code): which dK/dV kernel form a call
+    runs and how much scratch it asks for — the numbers DESIGN.md quotes for the headline — and the rule that a
+    BWD_COMPUTE / BWD_REDUCE pair and the sizing call agree because only the ARGUMENTS enter (ABI 4: the tuning
+    overrides are fields of the call; the process environment is not consulted by the library)."""
     from ring_flash_attn import _C
+    from ring_flash_attn import backend as BK
 
     lib = _C.load()
-    for k in ("RFA_DKDV_WIDE", "RFA_DKDV_NSPLIT"):
-        monkeypatch.delenv(k, raising=False)
 
-    def args(B, Sq, Sk, H, Hk, D=128, varlen_total=None, acc=False, phases=0, window=None, halves=(0, 0)):
+    def args(B, Sq, Sk, H, Hk, D=128, varlen_total=None, acc=False, phases=0, window=None, halves=(0, 0),
+             causal=False, form=0, nsplit=0):
         a = _C.BwdArgs()
         a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype = B, Sq, Sk, H, Hk, D, 0
         a.total_k = varlen_total if varlen_total is not None else B * Sk
@@ -210,38 +214,72 @@ def test_backward_plan_is_a_function_of_the_shapes(built, monkeypatch):
         if acc:
             a.dk_acc = a.dv_acc = 1
         a.phases = phases
+        a.causal = 1 if causal else 0
         a.q_half, a.k_half = halves
+        a.dkdv_form, a.dkdv_nsplit = form, nsplit
         if window:
             a.window, a.window_left, a.window_right = 1, window[0], window[1]
         return a
 
     unit = lambda rows, Hk, D=128: 2 * rows * Hk * D * 2        # one (dK, dV) partial set in the io dtype
+    unit32 = lambda rows, Hk, D=128: 2 * rows * Hk * D * 4      # ... in fp32 (the partials of a split launch)
     ws = lambda a: lib.rfa_bwd_workspace_bytes(C.byref(a))
     ds = lambda a: lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
-    # headline (GQA 32:8, S = 8192): 256-key form, two workgroups per key block -> two partial sets
-    assert ws(args(1, 8192, 8192, 32, 8)) == 2 * unit(8192, 8)
+
+    def plan(a):
+        f, n, g = C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.rfa_bwd_plan(C.byref(a), C.byref(f), C.byref(n), C.byref(g)) == 0
+        return f.value, n.value
+
+    # headline (GQA 32:8, S = 8192): 256-key form, two workgroups per key block -> two fp32 partial sets
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    assert ws(args(1, 8192, 8192, 32, 8, causal=True)) == 2 * unit32(8192, 8)
+    # dS scratch: rectangular rows when every block is visited, packed triangular rows for a dense causal call
     assert ds(args(1, 8192, 8192, 32, 8)) == 32 * 256 * 256 * 2048
+    assert ds(args(1, 8192, 8192, 32, 8, causal=True)) == 32 * (256 * 257 // 2) * 2048
+    # ... bottom-right aligned: 4096 queries x 8192 keys -> row qt holds 129 + qt blocks
+    assert ds(args(1, 4096, 8192, 2, 2, causal=True)) == 2 * sum(129 + qt for qt in range(128)) * 2048
+    # ... more queries than keys: the first (Sq - Sk) / 32 rows are empty
+    assert ds(args(1, 8192, 4096, 2, 2, causal=True)) == 2 * sum(max(0, qt - 127) for qt in range(256)) * 2048
+    # ... odd lengths
+    assert ds(args(1, 1000, 1000, 1, 1, causal=True)) == sum(min(32, qt + 1) for qt in range(32)) * 2048
     # MHA: 1024 workgroups already, no split -> plain outputs need no workspace; accumulate / phased calls do
+    assert plan(args(1, 8192, 8192, 32, 32, causal=True)) == (_C.DKDV_256, 1)
     assert ws(args(1, 8192, 8192, 32, 32)) == 0
     assert ws(args(1, 8192, 8192, 32, 32, acc=True)) == unit(8192, 32)
     assert ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_COMPUTE)) == ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_REDUCE))
     # ring "front" step of world size 8 (all queries x 4096 keys): four workgroups per key block
-    assert ws(args(1, 8192, 4096, 32, 8)) == 4 * unit(4096, 8)
+    assert ws(args(1, 8192, 4096, 32, 8)) == 4 * unit32(4096, 8)
     # small launches, head dim 64 and windows keep the 128-key form (no split, no workspace)
+    assert plan(args(1, 1024, 1024, 4, 2)) == (_C.DKDV_128, 1)
     assert ws(args(1, 1024, 1024, 4, 2)) == 0
     assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
     assert ws(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0 and ds(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0
-    # packed sequences: the form is chosen from the packed row count, the scratch from the longest sequence;
-    # half-sequence steps reserve half the blocks per axis
-    assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit(8192, 8)
-    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 3 * 32 * 231 * 231 * 2048
+    # packed sequences: the form is chosen from the packed row count, the scratch (rectangular rows, also when
+    # causal) from the longest sequence; half-sequence steps reserve half the blocks per axis
+    assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit32(8192, 8)
+    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True)) == 3 * 32 * 231 * 231 * 2048
     assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 3 * 32 * 116 * 116 * 2048
-    # the overrides
+    # the overrides are arguments ...
+    assert ws(args(1, 8192, 8192, 32, 8, form=_C.DKDV_128)) == 0
+    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == (_C.DKDV_256, 3)
+    assert ws(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == 3 * unit32(1024, 2)
+    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 2)    # (split count still by shape)
+    # ... the process environment does not reach the library
     monkeypatch.setenv("RFA_DKDV_WIDE", "0")
-    assert ws(args(1, 8192, 8192, 32, 8)) == 0
-    monkeypatch.setenv("RFA_DKDV_WIDE", "1")
     monkeypatch.setenv("RFA_DKDV_NSPLIT", "3")
-    assert ws(args(1, 1024, 1024, 4, 2)) == 3 * unit(1024, 2)
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    # ... it is translated once per backward by the Python backend (tests / tuning)
+    assert BK._plan_overrides() == (_C.DKDV_128, 3)
+    monkeypatch.setenv("RFA_DKDV_WIDE", "1")
+    assert BK._plan_overrides() == (_C.DKDV_256, 3)
+    monkeypatch.delenv("RFA_DKDV_WIDE")
+    monkeypatch.delenv("RFA_DKDV_NSPLIT")
+    assert BK._plan_overrides() == (_C.DKDV_AUTO, 0)
+    # invalid plan fields are rejected
+    bad = args(1, 64, 64, 1, 1, form=7)
+    bad.dout = bad.q = bad.k = bad.v = bad.lse = bad.delta = bad.dq = bad.dk = bad.dv = 16
+    assert lib.rfa_bwd(C.byref(bad), None) == -8
 
 
 def test_bench_accounting_matches_the_survey():

@@ -35,11 +35,11 @@ def test_zigzag_fp32_wire_matches_golden(W, monkeypatch):
 
 @pytest.mark.parametrize("W", [2, 4])
 def test_zigzag_gather_without_the_kv_cache_matches_golden(W, monkeypatch):
-    """RFA_ZIGZAG_KV_CACHE=0: the backward gathers K/V again and keeps the local-block-first order (the default —
+    """RFA_ZIGZAG_KV_KEEP=0: the backward gathers K/V again and keeps the local-block-first order (the default —
     K/V kept from the forward, remote steps first, local block beside the all-to-all — is what the tests above
     run)."""
     monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")
-    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE", "0")
+    monkeypatch.setenv("RFA_ZIGZAG_KV_KEEP", "0")
     names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
     errs = RW.run_world(W, names, use_hip=False, port=free_port())
     assert not errs, "\n".join(errs)
@@ -55,45 +55,21 @@ def test_zigzag_under_activation_checkpointing_matches_golden(monkeypatch):
     assert not errs, "\n".join(errs)
 
 
-def test_kv_cache_follows_the_autograd_state():
-    """the gathered K/V are kept exactly when a backward will follow: not under torch.no_grad(), not for inputs
-    without requires_grad; and the backward consumes the entry"""
+def test_kept_kv_is_owned_by_the_autograd_graph():
+    """the K/V gathered by the zigzag forward are SAVED TENSORS of its autograd node: present exactly when a backward
+    can follow (not under torch.no_grad(), not for inputs without requires_grad), freed with the graph, not kept over
+    RFA_ZIGZAG_KV_KEEP_BYTES / with RFA_ZIGZAG_KV_KEEP=0 (the backward then gathers again, same gradients).  No
+    process-global state is involved (round-2 review)."""
     import torch.multiprocessing as mp
     import _kv_cache_worker as KW
+    from ring_flash_attn import zigzag_ring_flash_attn as Z, utils as U
 
+    assert not hasattr(Z, "_KV_CACHE") and not hasattr(U, "_BACKWARD_EXPECTED") and not hasattr(U, "_GRAD_MODE_AT_CALL")
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(KW.run, args=(2, free_port(), ret), nprocs=2, join=True)
-    assert ret[0] == [1, 0, 0, 0] and ret[1] == [1, 0, 0, 0], dict(ret)
-
-
-def test_kv_cache_entries_are_matched_and_bounded(monkeypatch):
-    """the forward -> backward K/V cache of the zigzag gather form: taken exactly once, missed after an in-place
-    update of k, evicted oldest-first beyond RFA_ZIGZAG_KV_CACHE_BYTES, switched off by RFA_ZIGZAG_KV_CACHE=0"""
-    import torch
-    from ring_flash_attn import zigzag_ring_flash_attn as Z
-
-    Z._KV_CACHE.clear()
-    k, v = torch.randn(1, 16, 2, 8), torch.randn(1, 16, 2, 8)
-    ka, va = torch.randn(2, 1, 16, 2, 8), torch.randn(2, 1, 16, 2, 8)
-    Z._kv_cache_put(None, k, v, 2, 0, ka, va)
-    got = Z._kv_cache_take(None, k, v, 2, 0)
-    assert got is not None and got[0] is ka and Z._kv_cache_take(None, k, v, 2, 0) is None
-    Z._kv_cache_put(None, k, v, 2, 0, ka, va)
-    k.add_(1.0)                                                   # version bump: the gathered copy is stale
-    assert Z._kv_cache_take(None, k, v, 2, 0) is None
-    Z._KV_CACHE.clear()
-    entry = 2 * 2 * k.numel() * k.element_size()
-    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE_BYTES", str(2 * entry))
-    ks = [torch.randn(1, 16, 2, 8) for _ in range(3)]
-    for t in ks:
-        Z._kv_cache_put(None, t, v, 2, 0, ka, va)
-    assert len(Z._KV_CACHE) == 2 and Z._kv_cache_take(None, ks[0], v, 2, 0) is None      # oldest evicted
-    assert Z._kv_cache_take(None, ks[2], v, 2, 0) is not None
-    monkeypatch.setenv("RFA_ZIGZAG_KV_CACHE", "0")
-    Z._kv_cache_put(None, ks[0], v, 2, 0, ka, va)
-    assert Z._kv_cache_take(None, ks[0], v, 2, 0) is None
-    Z._KV_CACHE.clear()
+    want = [6, True, None, None, 5, True, 5, True]
+    assert ret[0] == want and ret[1] == want, dict(ret)
 
 
 def test_packed_pair_recognises_only_adjacent_halves_of_one_buffer():
@@ -158,6 +134,21 @@ def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
     assert names
     errs = RW.run_world(W, names, use_hip=False, port=free_port())
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_schedules_under_torch_compile_at_world_size_gt_1(W, monkeypatch):
+    """the reference's second test pass (test/test.sh:23-25: every test again with the function compiled, at the full
+    world size).  Multi-rank schedules are graph breaks by design (`torch.compiler.disable`); a compiled caller
+    must reproduce the golden vectors AND the plain call bit for bit — for both exchange forms of the zigzag path."""
+    monkeypatch.setenv("RFA_TEST_COMPILE", "1")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and "sample" not in c]
+    assert names
+    for mode in ("gather", "ring"):
+        monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
+        sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
+        errs = RW.run_world(W, sel, use_hip=False, port=free_port())
+        assert not errs, "\n".join(errs)
 
 
 def test_unmodified_reference_runs_on_the_flash_attn_shim():
