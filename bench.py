@@ -11,9 +11,10 @@ A "step" = one forward + one backward of that operator on every rank (grad reset
 
 Prints ONE JSON line (rank 0).  `value` = iterations/s of the whole job (max time over ranks).
 At every N the line carries
-  * `roofline`   the dominant kernel (largest device time per launch) against the bf16 MFMA peak, timed
-                 with device events on the launch stream on rank 0, on this rank's step-0 (local causal)
-                 block — the same launch at every world size;
+  * `roofline`   the dominant kernel (largest device time per launch) against the bf16 MFMA peak, timed with
+                 HIP events INSIDE the real step at N = 1 (`kernels_in_step`: events between the launches of the
+                 public function's own call sequence; their sum must stay below `ms_per_step`), and on this
+                 rank's step-0 (local causal) block on its own at N > 1 — the same launch at every world size;
   * `comm`       (N > 1) exchange form, bytes per rank per iteration, and `exposed_ms` = measured step minus
                  the same rank-local kernel sequence with the exchange looped back to local buffers
                  (ring_flash_attn.utils.set_loopback), max over ranks;
@@ -111,19 +112,18 @@ def kernel_breakdown(q, kv, dout, cu=None):
     return t
 
 
-def kernels_digest():
-    """content hash of the device sources: profiles/*traffic.json is only valid for the kernels it was measured on"""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "ring-flash-attention_amd", "csrc")
-    for n in sorted(os.listdir(d)):
-        if n.endswith((".hip", ".hpp", ".cpp")):
-            h.update(open(os.path.join(d, n), "rb").read())
-    return h.hexdigest()[:16]
+def library_digest():
+    """sha256 (first 16 hex digits) of the librfa_hip.so this process loads: profiles/*_traffic.json carries the
+    digest of the BINARY its counters were collected on (written on the GPU box by profiles/collect_pmc.sh at
+    collection time), and is only quoted when it is this binary"""
+    from ring_flash_attn import _C
+
+    return hashlib.sha256(open(_C.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def committed_traffic(kernel, hk):
     """HBM bytes per launch from the committed PMC pass (counters cannot be collected inside the timed process).
-    Returns (bytes or None, note)."""
+    Returns (entry or None, note)."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for n in sorted(os.listdir(pdir)):
@@ -132,14 +132,96 @@ def committed_traffic(kernel, hk):
     if best is None or hk != 8:
         return None, "no PMC traffic pass committed for this configuration"
     tr = json.load(open(os.path.join(pdir, best)))
-    if tr.get("kernels_sha16") != kernels_digest():
-        sys.stderr.write(f"bench.py: profiles/{best} was collected on different kernel sources "
-                         f"({tr.get('kernels_sha16')} vs {kernels_digest()}): roofline.traffic withheld — "
-                         f"re-run profiles/collect_pmc.sh\n")
-        return None, f"profiles/{best} is stale for the current kernel sources (re-run profiles/collect_pmc.sh)"
+    have = tr.get("library_sha16")
+    if have != library_digest():
+        sys.stderr.write(f"bench.py: profiles/{best} was collected on another build of librfa_hip.so "
+                         f"({have} vs {library_digest()}): roofline.traffic withheld — re-run profiles/collect_pmc.sh\n")
+        return None, f"profiles/{best} is stale for this librfa_hip.so (re-run profiles/collect_pmc.sh)"
     if kernel not in tr:
         return None, f"profiles/{best} has no entry for {kernel}"
-    return tr[kernel]["hbm_bytes_per_launch"], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"
+    return tr[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
+
+
+class _Hip:
+    """the few HIP runtime calls the in-step timer needs (raw events: the C ABI takes hipEvent_t handles)"""
+
+    def __init__(self):
+        import ctypes as C
+
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+        self.lib.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.lib.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.lib.hipEventDestroy.argtypes = [C.c_void_p]
+
+    def event(self):
+        e = self.C.c_void_p()
+        assert self.lib.hipEventCreate(self.C.byref(e)) == 0
+        return e
+
+    def record(self, e):
+        assert self.lib.hipEventRecord(e, self.C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+
+    def ms(self, e0, e1):
+        self.lib.hipEventSynchronize(e1)
+        t = self.C.c_float()
+        assert self.lib.hipEventElapsedTime(self.C.byref(t), e0, e1) == 0
+        return t.value
+
+
+class InStepTimer:
+    """Backend wrapper that times every launch INSIDE the real step: the public function runs unchanged — same
+    launches, same stream, same order, same data — with HIP events recorded between the launches (before / after
+    every backend call; inside rfa_bwd by the library itself through rfa_bwd_args.prof_events: after its first
+    kernel, its second kernel and the reduction pass).  Installed through ring_flash_attn.backend.set_backend for a
+    few extra steps after the timed region; the timed region itself runs the plain backend."""
+
+    def __init__(self, be):
+        self.be, self.hip, self.calls = be, _Hip(), []
+
+    def __getattr__(self, name):
+        fn = getattr(self.be, name)
+        if name not in ("fwd", "bwd_preprocess", "cast", "sum_slots", "merge"):
+            return fn
+
+        def timed(*a, **kw):
+            e0, e1 = self.hip.event(), self.hip.event()
+            self.hip.record(e0)
+            r = fn(*a, **kw)
+            self.hip.record(e1)
+            self.calls.append((name, e0, e1))
+            return r
+
+        return timed
+
+    def bwd(self, *a, **kw):
+        ev = (self.hip.C.c_void_p * 4)(*[self.hip.event() for _ in range(4)])
+        r = self.be.bwd(*a, prof_events=ev, **kw)
+        self.calls.append(("bwd", ev, None))
+        return r
+
+    def totals(self, spill):
+        """{launch name: (ms summed over the recorded steps, launches)}"""
+        first, second = ("bwd_dkdv", "bwd_dq") if spill else ("bwd_dq", "bwd_dkdv")
+        tot = {}
+
+        def add(n, ms):
+            t = tot.setdefault(n, [0.0, 0])
+            t[0] += ms
+            t[1] += 1
+
+        for name, e0, e1 in self.calls:
+            if name == "bwd":
+                add(first, self.hip.ms(e0[0], e0[1]))
+                add(second, self.hip.ms(e0[1], e0[2]))
+                red = self.hip.ms(e0[2], e0[3])
+                if red > 1e-3:
+                    add("bwd_reduce", red)
+            else:
+                add(name, self.hip.ms(e0, e1))
+        return tot
 
 
 def cpu_model():
@@ -153,12 +235,17 @@ def cpu_model():
 
 
 def cpu_baseline(hk, full):
-    """The CPU oracle (a port: oracle/flash_attn_ref.py, the restated flash_attn arithmetic the reference would
-    run per block; at world size 1 the reference's zigzag schedule is exactly one such block, one first-block
-    merge (a copy) and one cast — /root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:28-88 — and the
-    reference tree itself does not exist on the GPU box).  Default: a bounded sample — ONE kv-head group (H/Hk
-    q heads) at the full S = 8192 causal shape, fwd+bwd, after a warm-up pass on a quarter-length problem —
-    scaled by the number of groups and labelled extrapolated.  --cpu-baseline-full times all groups."""
+    """The reference's CPU path, timed on this box's host cores.
+
+    kind "reference": when /root/reference exists (the build container — it does not travel to the GPU box), the
+    UNMODIFIED reference schedule (ring_flash_attn/zigzag_ring_flash_attn.py:7-199 through its autograd Function) runs
+    under gloo at world size 1 with the oracle standing in for its `flash_attn` import, exactly as BASELINE.md
+    prescribes.  kind "port" (the GPU box): the oracle's _flash_attn_forward/_backward called directly — at world
+    size 1 the reference's zigzag schedule IS one such call plus a first-block merge (a copy) and two casts
+    (zigzag_ring_flash_attn.py:28-88), so the two kinds time the same arithmetic.
+    Default: a bounded sample — ONE kv-head group (H/Hk q heads) at the full S = 8192 causal shape, fwd+bwd, after a
+    warm-up pass on a quarter-length problem — scaled by the number of groups and labelled extrapolated (heads are
+    independent).  --cpu-baseline-full times all groups in one pass."""
     from oracle import flash_attn_ref as O
 
     g = HEADS // hk
@@ -169,8 +256,25 @@ def cpu_baseline(hk, full):
     v = torch.randn(1, SEQ, groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
     do = torch.randn(1, SEQ, g * groups, HEAD_DIM, generator=gen).to(torch.bfloat16)
     scale = HEAD_DIM ** -0.5
+    kind = "port"
+    ref_fn = None
+    try:
+        from oracle import reference_harness
+
+        if reference_harness.available():
+            mods = reference_harness.load_reference(provider="oracle")
+            for m in mods.values():
+                ref_fn = getattr(m, "zigzag_ring_flash_attn_func", ref_fn)
+            kind = "reference" if ref_fn is not None else "port"
+    except Exception:
+        ref_fn = None
 
     def once(n):
+        if ref_fn is not None:
+            qq, kk, vv = (t[:, :n].clone().requires_grad_(True) for t in (q, k, v))
+            out = ref_fn(qq, kk, vv, causal=True)
+            out.backward(do[:, :n])
+            return
         out, lse, _, _ = O._flash_attn_forward(q[:, :n], k[:, :n], v[:, :n], 0.0, scale, True)
         dq, dk, dv = torch.empty_like(q[:, :n]), torch.empty_like(k[:, :n]), torch.empty_like(v[:, :n])
         O._flash_attn_backward(do[:, :n], q[:, :n], k[:, :n], v[:, :n], out, lse, dq, dk, dv, 0.0, scale, True)
@@ -186,7 +290,7 @@ def cpu_baseline(hk, full):
         "cores": torch.get_num_threads(),
         "host_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
-        "kind": "port",
+        "kind": kind,
         "extrapolated": not full,
         "sample": (f"all {hk} kv-head groups, full S={SEQ} causal fwd+bwd, one timed pass after a warm-up ({dt:.2f} s)"
                    if full else
@@ -220,6 +324,9 @@ def main():
                     help="N=1 only: additionally time rank --virtual-rank's kernel sequence of a job of this world size "
                          "with the exchange looped back to local buffers (compute-only cost of the multi-step path)")
     ap.add_argument("--virtual-rank", type=int, default=-1)
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="N > 1, dense zigzag, exchange 'auto': skip the measured choice between the exchange forms "
+                         "(ring_flash_attn.tuning.autotune_zigzag_exchange in the warm-up) and use the shape rule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time all kv-head groups (about 8x longer)")
     ap.add_argument("--no-breakdown", action="store_true")
@@ -326,6 +433,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return tmax.item()
 
+    # ---- N > 1: let the group MEASURE which exchange form is faster here (a few fwd+bwd in each form on scratch
+    # tensors of the workload's shapes, max over ranks, same decision on every rank) instead of trusting a default
+    # that has never run on this node; a form that fails is disqualified, not fatal.  Untimed, reported in `comm`.
+    tune_rep, probe_rep = None, None
+    if multi and wl == "zigzag" and not args.no_autotune and os.environ.get("RFA_ZIGZAG_EXCHANGE", "auto").lower() == "auto":
+        from ring_flash_attn import tuning
+
+        kd, vd = kv.detach()[:, :, 0], kv.detach()[:, :, 1]
+        tune_rep = tuning.autotune_zigzag_exchange(None, q.detach(), kd, vd, iters=3, warm=2)
+    if multi:
+        from ring_flash_attn import tuning
+
+        try:
+            probe_rep = tuning.comm_probe(None, dev, 2 * SEQ * hk * HEAD_DIM * 2)   # K + V of one rank
+        except Exception as e:           # the probe must never sink the benchmark
+            probe_rep = {"error": f"{type(e).__name__}: {e}"}
+
     # device spin-up (not a measurement knob): the MI355X needs some tens of milliseconds of load to leave
     # its idle clocks; without it the W warm-up steps (W x ~2 ms) end while the clocks are still ramping and
     # the timed region measures the ramp, not the kernels.  Untimed, bounded, reported in the JSON line.
@@ -381,7 +505,7 @@ def main():
     if forced:
         result["forced_rccl_world1"] = "N > 1 code path on a one-rank RCCL group (test only, not a measurement)"
     if multi:
-        mode = exchange_mode(kv.detach()[:, :, 0], world) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
+        mode = exchange_mode(kv.detach()[:, :, 0], world, q.detach()) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
         rfa_utils.set_loopback((rank, world))
         try:
             for _ in range(2):
@@ -398,6 +522,8 @@ def main():
             "bytes_sent_per_rank_per_iter": comm_bytes_per_iter(mode, _wire_fp32(), world, hk) if wl == "zigzag" else None,
             "compute_only_ms": comp,
             "exposed_ms": ms - comp,
+            "autotune": tune_rep,
+            "probe": probe_rep,
             "note": "compute_only = this rank's exact kernel sequence with the exchange looped back to local buffers "
                     "(ring_flash_attn.utils.set_loopback), max over ranks; exposed = ms_per_step - compute_only",
         }
@@ -420,23 +546,65 @@ def main():
                     "ideal = world x the measured world-size-1 step",
         }
 
-    if rank == 0 and not args.no_breakdown:
+    # ---- kernel times INSIDE the step (every rank runs the instrumented steps: collectives must stay matched)
+    instep = None
+    if not args.no_breakdown:
+        from ring_flash_attn import backend as rfa_backend
+
+        timer = InStepTimer(rfa_backend.get_backend())
+        rfa_backend.set_backend(timer)
+        nprof = max(1, min(args.steps, 10))
+        try:
+            step()                                   # (events and the wrapper warm)
+            torch.cuda.synchronize()
+            timer.calls = []
+            counter[0] = 0
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+        finally:
+            rfa_backend.set_backend(None)
+        spill = os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
+        tot = timer.totals(spill)
+        instep = {n: {"ms_per_step": t[0] / nprof, "launches_per_step": t[1] / nprof, "avg_launch_ms": t[0] / t[1]}
+                  for n, t in tot.items()}
+
+    if rank == 0 and instep is not None:
         with torch.no_grad():
             if wl == "zigzag":
-                t = kernel_breakdown(q.detach(), kv.detach(), dout)
+                iso = kernel_breakdown(q.detach(), kv.detach(), dout)
                 f = causal_fwd_flops([SEQ])
             else:
                 cu_b = torch.tensor(VARLEN_PATTERNS[1], device=dev, dtype=torch.int32)
-                t = kernel_breakdown(q.detach(), kv.detach(), dout, cu_b)
+                iso = kernel_breakdown(q.detach(), kv.detach(), dout, cu_b)
                 f = causal_fwd_flops([b - a for a, b in zip(VARLEN_PATTERNS[1][:-1], VARLEN_PATTERNS[1][1:])])
-        # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
-        # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of
-        # S and dP inside the dQ kernel is NOT credited)
-        algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
-        dom = max(algo, key=lambda n: t[n])
-        ach = algo[dom] / (t[dom] * 1e-3) / 1e12
-        kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_kernel"}[dom]
-        traffic, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
+        sum_ms = sum(v_["ms_per_step"] for v_ in instep.values())
+        result["kernels_in_step"] = {
+            "ms": {n: round(v_["ms_per_step"], 4) for n, v_ in instep.items()},
+            "launches": {n: v_["launches_per_step"] for n, v_ in instep.items()},
+            "sum_ms": round(sum_ms, 4),
+            "ms_per_step": round(ms, 4),
+            "other_ms": round(ms - sum_ms, 4),
+            "consistent": bool(sum_ms <= ms * 1.02),
+            "how": f"HIP events between the launches of the real step (InStepTimer: backend calls of the public "
+                   f"function, rfa_bwd_args.prof_events inside the backward), {nprof} instrumented steps after the "
+                   f"timed region; other_ms = ms_per_step - sum (host gaps, autograd, grad buffers)",
+        }
+        if world == 1 and wl == "zigzag":
+            # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
+            # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of S and dP
+            # inside the 7-GEMM dQ kernel is NOT credited)
+            algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+            t_in = {n: instep[n]["avg_launch_ms"] for n in algo if n in instep}
+        else:
+            # N > 1 / packed workloads: the step makes several launches of each kernel with different shapes; the
+            # roofline line is this rank's local causal block (step 0 of every world size), timed on its own
+            algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+            t_in = {n: iso[n] for n in algo}
+        dom = max(t_in, key=lambda n: t_in[n])
+        ach = algo[dom] / (t_in[dom] * 1e-3) / 1e12
+        kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_ds_kernel" if spill else "dq_kernel"}[dom]
+        entry, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
         result["roofline"] = {
             "kernel": kn,
             "launch": "this rank's local causal block (step 0 of every world size)",
@@ -445,12 +613,19 @@ def main():
             "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": traffic,
+            "traffic": entry["hbm_bytes_per_launch"] if entry else None,
+            "traffic_algorithmic": entry.get("algorithmic_bytes") if entry else None,
+            "traffic_handoff": entry.get("handoff_bytes") if entry else None,
             "traffic_source": note,
-            "avg_launch_ms": t[dom],
+            "avg_launch_ms": t_in[dom],
+            "timed": "in-step" if (world == 1 and wl == "zigzag") else "isolated launches of the local block",
         }
-        result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t.items()}
-        result["kernels_tflops"] = {n: algo[n] / (t[n] * 1e-3) / 1e12 for n in algo}
+        result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t_in.items()}
+        result["kernels_ms_isolated"] = {k2: round(v2, 4) for k2, v2 in iso.items()}
+        result["kernels_tflops"] = {n: algo[n] / (t_in[n] * 1e-3) / 1e12 for n in t_in}
+        bwd_ms = sum(instep[n]["ms_per_step"] for n in instep if n.startswith("bwd"))
+        if world == 1 and wl == "zigzag" and bwd_ms > 0:
+            result["backward_tflops"] = 2.5 * f / (bwd_ms * 1e-3) / 1e12
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
 

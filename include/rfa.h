@@ -178,6 +178,12 @@ typedef struct {
    *               (256-key form only)
    * A zero-initialised struct means "auto".  rfa_bwd_plan() reports what a call will run. */
   int32_t dkdv_form, dkdv_nsplit;
+  /* Measurement aid (NULL = off): 4 caller-owned hipEvent_t handles, recorded on `stream` before the first
+   * launch of the call and after its first kernel, its second kernel and the reduction pass (launches a call
+   * does not make record their event right behind the previous one).  Kernel order: dK/dV then dQ when the call
+   * runs the dS-spill form (rfa_bwd_plan: five_gemm), dQ then dK/dV otherwise.  This is how bench.py times the
+   * kernels INSIDE the real step instead of in isolation. */
+  void **prof_events;
 } rfa_bwd_args;
 
 enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };

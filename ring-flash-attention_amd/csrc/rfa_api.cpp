@@ -267,6 +267,10 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
   }
+  auto mark = [&](int i) {
+    if (a->prof_events && a->prof_events[i]) (void)hipEventRecord((hipEvent_t)a->prof_events[i], st);
+  };
+  mark(0);
   const bool do_compute = bwd_single_phase(a) || (a->phases & RFA_BWD_COMPUTE);
   const bool do_reduce = bwd_single_phase(a) || (a->phases & RFA_BWD_REDUCE);
   const int kv_init = (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE)) ? 1 : 0;
@@ -280,14 +284,21 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       p.ds_tri = p.ds_c < ds_blocks(a->Sk, a->k_half) ? 1 : 0;
       if (!(a->phases & RFA_BWD_SKIP_DKDV))
         if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
+      mark(1);
       if (!(a->phases & RFA_BWD_SKIP_DQ))
         if (int rc2 = launch_bwd_dq_from_ds(p, a->dtype, st)) return launch_status(rc2);
+      mark(2);
     } else {
       if (!(a->phases & RFA_BWD_SKIP_DQ))
         if (int rc2 = launch_bwd_dq(p, a->dtype, st)) return launch_status(rc2);
+      mark(1);
       if (!(a->phases & RFA_BWD_SKIP_DKDV))
         if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
+      mark(2);
     }
+  } else {
+    mark(1);
+    mark(2);
   }
   if (ws && do_reduce) {
     // dK and dV in one launch (grid z)
@@ -307,6 +318,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     }
     if (launch_reduce(r, a->dtype, st)) return RFA_ERR_LAUNCH;
   }
+  mark(3);
   return RFA_OK;
 }
 

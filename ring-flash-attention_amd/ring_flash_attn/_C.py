@@ -80,6 +80,7 @@ class BwdArgs(C.Structure):
         ("ds_scratch", C.c_void_p),
         ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
         ("dkdv_form", C.c_int32), ("dkdv_nsplit", C.c_int32),
+        ("prof_events", C.POINTER(C.c_void_p)),
     ]
 
 

@@ -137,7 +137,7 @@ class HipBackend:
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL,
             k_half=HALF_FULL, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None,
             acc_init=False, deterministic=False, phases=_C.BWD_ALL, partials=None, ds_scratch=None,
-            window=(-1, -1)):
+            window=(-1, -1), prof_events=None):
         """dQ/dK/dV of one block.  Plain outputs (io dtype) or `+=` into fp32 accumulators.
         phases=BWD_COMPUTE / BWD_REDUCE splits the call so a ring step can overlap the kernels
         with the arrival of the dk/dv accumulators it adds into: the COMPUTE call RETURNS the buffer
@@ -185,6 +185,8 @@ class HipBackend:
             a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         a.phases = phases
+        if prof_events is not None:       # measurement (bench.py): a ctypes array of 4 hipEvent_t, see include/rfa.h
+            a.prof_events = prof_events
         reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
         # dK/dV launch plan: part of the call (ABI 4).  The tuning / test overrides RFA_DKDV_WIDE, RFA_DKDV_NSPLIT are
         # read HERE, once per backward: a REDUCE call reuses the plan its COMPUTE call ran with (it travels with the

@@ -1,0 +1,169 @@
+"""Measured choice of the zigzag exchange form, and the communication probes behind it.
+
+The dense zigzag schedule has two exchange forms (zigzag_ring_flash_attn.py: `ring` = the reference's neighbour
+hops, /root/reference/ring_flash_attn/utils.py:98-151; `gather` = one all-gather + one all-to-all over the whole
+xGMI mesh).  Which one is faster depends on the node (links per GPU pair, RCCL version, how the RCCL kernels share the
+CUs with a 256-CU attention grid — SURVEY H3), so the default `auto` can be backed by a measurement:
+
+    autotune_zigzag_exchange(group, q, k, v)     runs the real forward + backward of the schedule a few times in each
+        form on scratch copies of the caller's shapes, takes the MAX over ranks of the per-iteration time (one
+        all_reduce, so every rank reaches the same decision) and records the winner for (shapes, dtype, world size).
+        `zigzag_ring_flash_attn.exchange_mode` consults that record before its shape rule.  A form that raises (a
+        collective the installed RCCL does not support: the same error on every rank) is disqualified and the other
+        one chosen instead of failing the job; a failure on some ranks only leaves the others inside the collective,
+        which no caller can repair.
+    comm_probe(group, device, nbytes)            achieved GB/s per rank of the three transfer kinds the schedules use
+        (all-gather, all-to-all, one neighbour hop) at a given message size.
+
+bench.py calls both in its warm-up at N > 1 and reports them in its `comm` block; tools/xgmi_probe.py is the
+stand-alone version.  The record is a tuning cache (like a GEMM autotuner's): written once per shape under a lock,
+read-only afterwards; it never holds tensors.
+"""
+import os
+import threading
+import time
+
+import torch
+import torch.distributed as dist
+
+_LOCK = threading.Lock()
+_TUNED = {}          # (world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
+_REPORTS = {}        # same key -> the measurement (for bench.py / logs)
+
+
+def _key(world, q_shape, k_shape, dtype):
+    B, S, H, D = q_shape
+    return (int(world), int(B), int(S), int(H), int(k_shape[2]), int(D), str(dtype))
+
+
+def lookup(q_shape, k_shape, dtype, world):
+    """the recorded exchange form for this problem, or None"""
+    return _TUNED.get(_key(world, q_shape, k_shape, dtype))
+
+
+def report(q_shape, k_shape, dtype, world):
+    return _REPORTS.get(_key(world, q_shape, k_shape, dtype))
+
+
+def clear():
+    with _LOCK:
+        _TUNED.clear()
+        _REPORTS.clear()
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
+def _max_over_ranks(value, group, dev):
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend(group) != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.item()
+
+
+def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "ring")):
+    """Time fwd + bwd of zigzag_ring_flash_attn_func in every exchange form on tensors shaped like (q, k, v) and
+    record the faster one.  Collective: every rank of `group` must call it with the same shapes.  Returns the
+    report dict {"chosen", "ms": {form: ms per iteration, max over ranks}, "failed": {...}}."""
+    from . import zigzag_ring_flash_attn as Z
+    from .utils import group_rank_world
+
+    world = group_rank_world(group)[1]
+    key = _key(world, q.shape, k.shape, q.dtype)
+    if key in _TUNED:
+        return _REPORTS[key]
+    dev = q.device
+    qs = torch.randn(q.shape, device=dev, dtype=torch.float32).to(q.dtype).requires_grad_(True)
+    ks = torch.randn(k.shape, device=dev, dtype=torch.float32).to(k.dtype).requires_grad_(True)
+    vs = torch.randn(v.shape, device=dev, dtype=torch.float32).to(v.dtype).requires_grad_(True)
+    do = torch.randn(q.shape, device=dev, dtype=torch.float32).to(q.dtype)
+    ms, failed = {}, {}
+    saved = os.environ.get("RFA_ZIGZAG_EXCHANGE")
+    try:
+        for mode in modes:
+            os.environ["RFA_ZIGZAG_EXCHANGE"] = mode
+            ok = 1.0
+            try:
+                def one():
+                    qs.grad = ks.grad = vs.grad = None
+                    out = Z.zigzag_ring_flash_attn_func(qs, ks, vs, causal=True, group=group)
+                    out.backward(do)
+
+                for _ in range(warm):
+                    one()
+                _sync(dev)
+                dist.barrier(group=group)
+                _sync(dev)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    one()
+                _sync(dev)
+                el = (time.perf_counter() - t0) / iters * 1e3
+            except Exception as e:          # a form that cannot run here loses; every rank learns it below
+                ok, el = 0.0, float("inf")
+                failed[mode] = f"{type(e).__name__}: {e}"
+            # all ranks agree: a failure anywhere disqualifies the form everywhere
+            bad = _max_over_ranks(1.0 - ok, group, dev)
+            ms[mode] = float("inf") if bad > 0 else _max_over_ranks(el, group, dev)
+    finally:
+        if saved is None:
+            os.environ.pop("RFA_ZIGZAG_EXCHANGE", None)
+        else:
+            os.environ["RFA_ZIGZAG_EXCHANGE"] = saved
+    finite = {m: t for m, t in ms.items() if t != float("inf")}
+    if not finite:
+        raise RuntimeError(f"autotune_zigzag_exchange: every exchange form failed: {failed}")
+    chosen = min(finite, key=finite.get)
+    rep = {"chosen": chosen, "ms": {m: (None if t == float("inf") else t) for m, t in ms.items()}, "failed": failed,
+           "iters": iters, "world": world}
+    with _LOCK:
+        _TUNED[key] = chosen
+        _REPORTS[key] = rep
+    if os.environ.get("RFA_TUNING_LOG", "0") == "1" and dist.get_rank(group) == 0:
+        import sys
+
+        sys.stderr.write(f"ring_flash_attn: zigzag exchange autotune {key}: {rep}\n")
+    return rep
+
+
+def comm_probe(group, device, nbytes, iters=5, warm=2):
+    """GB/s per rank (bytes this rank SENDS / time, max time over ranks) of an all-gather of `nbytes` per rank, an
+    all-to-all of `nbytes` per peer slot, and one neighbour hop of `nbytes` — the three transfers of the schedules.
+    Collective over `group`."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    gloo = dist.get_backend(group) == "gloo"
+    dev = torch.device("cpu") if gloo else device
+    n = max(1, nbytes // 2)
+    src = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    out = {}
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        _sync(dev)
+        dist.barrier(group=group)
+        _sync(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        _sync(dev)
+        return _max_over_ranks((time.perf_counter() - t0) / iters, group, dev)
+
+    gathered = torch.empty(world * n, dtype=torch.bfloat16, device=dev)
+    t = timed(lambda: dist.all_gather_into_tensor(gathered, src, group=group))
+    out["all_gather"] = {"bytes_sent": (world - 1) * n * 2, "ms": t * 1e3, "GBps": (world - 1) * n * 2 / t / 1e9 if world > 1 else None}
+    a2a_in, a2a_out = torch.zeros(world * n, dtype=torch.bfloat16, device=dev), torch.empty(world * n, dtype=torch.bfloat16, device=dev)
+    t = timed(lambda: dist.all_to_all_single(a2a_out, a2a_in, group=group))
+    out["all_to_all"] = {"bytes_sent": (world - 1) * n * 2, "ms": t * 1e3, "GBps": (world - 1) * n * 2 / t / 1e9 if world > 1 else None}
+    recv = torch.empty_like(src)
+    nxt = dist.get_global_rank(group, (rank + 1) % world) if group is not None else (rank + 1) % world
+    prv = dist.get_global_rank(group, (rank - 1) % world) if group is not None else (rank - 1) % world
+
+    def hop():
+        for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, nxt, group=group), dist.P2POp(dist.irecv, recv, prv, group=group)]):
+            r.wait()
+
+    t = timed(hop)
+    out["neighbour_hop"] = {"bytes_sent": n * 2, "ms": t * 1e3, "GBps": n * 2 / t / 1e9}
+    return out

@@ -63,11 +63,20 @@ def _wire_fp32() -> bool:
     return mode == "fp32"
 
 
-def exchange_mode(k: torch.Tensor, world: int) -> str:
+def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None) -> str:
+    """RFA_ZIGZAG_EXCHANGE = gather | ring forces a form.  auto (default): the form a measurement on this group
+    recorded for these shapes (tuning.autotune_zigzag_exchange — bench.py runs it in its warm-up), else gather while
+    its O(S_total) scratch stays below RFA_GATHER_MAX_BYTES, ring beyond.  Shapes only: every rank decides alike."""
     mode = os.environ.get("RFA_ZIGZAG_EXCHANGE", "auto").lower()
     if mode not in ("auto", "gather", "ring"):
         raise ValueError(f"RFA_ZIGZAG_EXCHANGE must be 'auto', 'gather' or 'ring', got {mode!r}")
     if mode == "auto":
+        if q is not None:
+            from . import tuning
+
+            tuned = tuning.lookup(q.shape, k.shape, q.dtype, world)
+            if tuned is not None:
+                return tuned
         limit = int(os.environ.get("RFA_GATHER_MAX_BYTES", str(4 << 30)))
         mode = "gather" if gather_scratch_bytes(k, world, _wire_fp32()) <= limit else "ring"
     return mode
@@ -147,7 +156,7 @@ def zigzag_ring_flash_attn_forward(
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, comm.world_size) == "gather":
+    if exchange_mode(k, comm.world_size, q) == "gather":
         gather, bufs, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
@@ -229,7 +238,7 @@ def zigzag_ring_flash_attn_backward(
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, kv_comm.world_size) == "gather":
+    if exchange_mode(k, kv_comm.world_size, q) == "gather":
         W, rank = kv_comm.world_size, kv_comm.rank
         wire32 = _wire_fp32()
         if kept:

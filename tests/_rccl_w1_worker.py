@@ -20,11 +20,12 @@ BF = torch.bfloat16
 
 
 def check(name, got, ref, atol, rtol=0.0):
-    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
-    assert got.shape == ref.shape, f"{name}: {got.shape} vs {ref.shape}"
-    diff = (got - ref).abs().max().item()
-    lim = atol + rtol * ref.abs().max().item()
-    assert diff <= lim, f"{name}: max|err| {diff:.3e} > {lim:.3e}"
+    """all criteria of tests/_tol.py (multi-step path: the *_ring bounds); kind from the call site's historical pair"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _tol
+
+    kind = {(2e-2, 0.0): "out_ring", (1e-3, 0.0): "lse_ring", (1e-2, 2e-2): "grad_ring"}[(atol, rtol)]
+    _tol.compare(name, got, ref, kind)
 
 
 def main(port):

@@ -17,6 +17,13 @@ BF = torch.bfloat16
 
 
 def _check(name, got, ref, atol, rtol=0.0):
+    """all criteria of tests/_tol.py; the kind follows from the historical (atol, rtol) pair of the call site:
+    (2e-2, 0) out, (1e-3, 0) lse, (1e-2, 2e-2) gradients — single-rank bounds"""
+    import _tol
+
+    kind = {(2e-2, 0.0): "out", (1e-3, 0.0): "lse", (1e-2, 2e-2): "grad"}.get((atol, rtol))
+    if kind is not None:
+        return _tol.compare(name, got, ref, kind + "")
     got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
     assert got.shape == ref.shape, f"{name}: {got.shape} vs {ref.shape}"
     diff = (got - ref).abs().max().item()

@@ -15,6 +15,23 @@ pytestmark = pytest.mark.gpu
 S, H, HK, D = 8192, 32, 8, 128
 
 
+def _row(name, i, h, got, ref):
+    """one sampled row (128 values) against its exact fp64 value: RELATIVE to the row itself — late rows of a long
+    causal sequence have |out| ~ 0.02, where an absolute bound would hide a systematic error — plus the
+    element-wise bound; the io dtype's rounding alone is 2^-9 ~ 2e-3 relative"""
+    import os
+
+    err = (got - ref)
+    rel = (err.norm() / ref.norm().clamp_min(1e-30)).item()
+    mx = err.abs().max().item()
+    path = os.environ.get("RFA_TOL_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"row        rel-norm {rel:.3e} max_err {mx:.3e} max_ref {ref.abs().max().item():.3e}  headline.{name}[{i},{h}]\n")
+    assert rel <= 1e-2, f"{name}[{i},{h}]: relative error of the row {rel:.3e} > 1e-2"
+    assert mx <= 2e-3 + 1.6e-2 * ref.abs().max().item(), f"{name}[{i},{h}]: max|err| {mx:.3e}"
+
+
 def _inputs(dev):
     g = torch.Generator().manual_seed(42)
     q = torch.randn(1, S, H, D, generator=g).to(torch.bfloat16)
@@ -45,12 +62,12 @@ def test_headline_sampled_rows(single_rank_group):
         p = torch.exp(s - l)
         o = p @ vf[0, : i + 1, hk]
         assert abs(l - lse[0, h, i]) < 1e-3
-        assert (o - out[0, i, h]).abs().max() < 1e-2
+        _row("out", i, h, out[0, i, h], o)
         dp = vf[0, : i + 1, hk] @ dof[0, i, h]
         delta = (dof[0, i, h] * out[0, i, h]).sum()
         ds = p * (dp - delta) * scale
         ref_dq = ds @ kf[0, : i + 1, hk]
-        assert (ref_dq - dq[0, i, h]).abs().max() < 5e-3 + 2e-2 * ref_dq.abs().max()
+        _row("dq", i, h, dq[0, i, h], ref_dq)
     for j in [0, 1000, S - 1]:
         hk = int(torch.randint(0, HK, (1,), generator=g))
         dk, dv = torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
@@ -62,8 +79,8 @@ def test_headline_sampled_rows(single_rank_group):
             ds = p * (dp - delta) * scale
             dk += ds @ qf[0, j:, h]
             dv += p @ dof[0, j:, h]
-        assert (dk - dkv[0, j, 0, hk]).abs().max() < 5e-3 + 2.5e-2 * dk.abs().max()
-        assert (dv - dkv[0, j, 1, hk]).abs().max() < 5e-3 + 2.5e-2 * dv.abs().max()
+        _row("dk", j, hk, dkv[0, j, 0, hk], dk)
+        _row("dv", j, hk, dkv[0, j, 1, hk], dv)
 
 
 def test_headline_constant_v_and_split_merge(single_rank_group):
@@ -120,11 +137,11 @@ def test_max_length_65536_single_gpu(single_rank_group):
         p = torch.exp(s - l)
         o = p @ vf[0, : i + 1, hk]
         assert abs(l - lse[0, h, i]) < 1e-3
-        assert (o - out[0, i, h]).abs().max() < 1e-2
+        _row("out", i, h, out[0, i, h], o)
         dp = vf[0, : i + 1, hk] @ dof[0, i, h]
         delta = (dof[0, i, h] * out[0, i, h]).sum()
         ref_dq = (p * (dp - delta) * scale) @ kf[0, : i + 1, hk]
-        assert (ref_dq - dq[0, i, h]).abs().max() < 5e-3 + 2e-2 * ref_dq.abs().max()
+        _row("dq", i, h, dq[0, i, h], ref_dq)
     j, hk = 60000, 1
     dk, dv = torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
     for h in range(hk * (HH // HKK), (hk + 1) * (HH // HKK)):
@@ -135,5 +152,5 @@ def test_max_length_65536_single_gpu(single_rank_group):
         ds = p * (dp - delta) * scale
         dk += ds @ qf[0, j:, h]
         dv += p @ dof[0, j:, h]
-    assert (dk - dkv[0, j, 0, hk]).abs().max() < 5e-3 + 2.5e-2 * dk.abs().max()
-    assert (dv - dkv[0, j, 1, hk]).abs().max() < 5e-3 + 2.5e-2 * dv.abs().max()
+    _row("dk", j, hk, dkv[0, j, 0, hk], dk)
+    _row("dv", j, hk, dkv[0, j, 1, hk], dv)

@@ -107,6 +107,32 @@ def test_zigzag_varlen_gather_exchange_matches_golden(W, monkeypatch):
     assert not errs, "\n".join(errs)
 
 
+@pytest.mark.parametrize("break_gather", [False, True])
+def test_exchange_autotune_is_a_collective_decision(break_gather):
+    """ring_flash_attn.tuning.autotune_zigzag_exchange: times fwd+bwd of the zigzag schedule in both exchange forms on
+    the real group, every rank records the SAME winner (max over ranks), exchange_mode('auto') then follows the record
+    for exactly those shapes, an explicit RFA_ZIGZAG_EXCHANGE still wins, and a form that raises (an unsupported
+    collective) is disqualified instead of sinking the job (round-2 review: the default form had never run on the
+    driver's 8-GPU node)."""
+    import torch.multiprocessing as mp
+    import _tuning_worker as TW
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(TW.run, args=(2, free_port(), ret, break_gather), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["before"] == b["before"] == "gather"                 # the shape rule
+    assert a["chosen"] == b["chosen"] == a["after"] == b["after"]
+    assert a["forced"] == b["forced"] == "ring" and a["other_shape"] == "gather"
+    assert a["ms"] == b["ms"]                                     # max over ranks: identical on both
+    if break_gather:
+        assert a["chosen"] == "ring" and a["ms"]["gather"] is None and "gather" in a["failed"] and "gather" in b["failed"]
+    else:
+        assert all(v_ is not None and v_ > 0 for v_ in a["ms"].values())
+        for kind in ("all_gather", "all_to_all", "neighbour_hop"):
+            assert a["probe"][kind]["GBps"] > 0 and a["probe"][kind]["ms"] == b["probe"][kind]["ms"]
+
+
 def test_exchange_mode_auto_threshold(monkeypatch):
     """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
     import torch
