@@ -112,6 +112,19 @@ typedef struct {
    * a negative value leaves that side unbounded; `causal` forces window_right = 0.  Only honoured when
    * `window` is non-zero, so that a zero-initialised struct means "no window". */
   int32_t window, window_left, window_right;
+  /* Dropout (flash_attn's dropout_p; the reference forwards it on the llama3 path,
+   * /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:131,135,266).  dropout_p = 0: off.  An attention
+   * probability is kept with probability keep/256, keep = round((1 - dropout_p) * 256), and kept ones are scaled by
+   * 1 / (1 - dropout_p); lse is that of the undropped softmax (flash_attn semantics).  The keep mask is a pure
+   * function of (dropout_seed, batch, head_offset + head, q_pos_offset + query position, k_pos_offset + key
+   * position) — csrc/rfa_common.hpp: drop_word — where a position is the row inside the dense sequence, or the
+   * absolute row of the packed tensor for cu_seqlens input; a rank that holds rows [a, b) of a longer stream passes
+   * a / the first gathered key row as offsets and gets the same bits as an unsharded call.  The backward must be
+   * given the forward's values.  Not available together with a window (RFA_ERR_ARGS). */
+  float dropout_p;
+  uint64_t dropout_seed;
+  int64_t q_pos_offset, k_pos_offset;
+  int32_t head_offset;
 } rfa_fwd_args;
 
 typedef struct {
@@ -184,6 +197,11 @@ typedef struct {
    * runs the dS-spill form (rfa_bwd_plan: five_gemm), dQ then dK/dV otherwise.  This is how bench.py times the
    * kernels INSIDE the real step instead of in isolation. */
   void **prof_events;
+  /* dropout: as in rfa_fwd_args, with the forward's values (a call with dropout runs the 7-GEMM form) */
+  float dropout_p;
+  uint64_t dropout_seed;
+  int64_t q_pos_offset, k_pos_offset;
+  int32_t head_offset;
 } rfa_bwd_args;
 
 enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };

@@ -32,6 +32,18 @@ inline int launch_status(int rc) {
 
 inline int eff_len(int S, int half) { return half == RFA_HALF_FULL ? S : (S + 1) / 2; }
 
+// dropout_p -> keep threshold in 1/256 (256 = nothing dropped) — csrc/rfa_common.hpp: drop_keep
+inline unsigned drop_threshold(float p) {
+  if (!(p > 0.f)) return 256u;
+  const int k = (int)((1.f - p) * 256.f + 0.5f);
+  return (unsigned)(k < 0 ? 0 : (k > 255 ? 255 : k));      // p > 0 always drops something
+}
+inline bool drop_args_ok(float p, int window, int wl, int wr, int causal) {
+  if (!(p >= 0.f) || p >= 1.f) return false;
+  const bool win = window && (wl >= 0 || (wr >= 0 && !causal));
+  return !(p > 0.f && win);
+}
+
 }  // namespace
 
 extern "C" {
@@ -48,7 +60,7 @@ const char* rfa_strerror(int status) {
     case RFA_ERR_SHAPE: return "negative or inconsistent extent";
     case RFA_ERR_ALIGN: return "pointer/stride violates the 16-byte alignment contract";
     case RFA_ERR_LAUNCH: return "HIP kernel launch failed";
-    case RFA_ERR_ARGS: return "inconsistent flag / pointer combination";
+    case RFA_ERR_ARGS: return "inconsistent flag / pointer combination (or dropout together with a window, dropout_p outside [0, 1))";
     case RFA_ERR_ATTR: return "could not opt the kernel into its dynamic LDS size on this device";
     default: return "unknown rfa status";
   }
@@ -67,6 +79,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
     return RFA_ERR_NULL;
   }
   if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
+  if (!drop_args_ok(a->dropout_p, a->window, a->window_left, a->window_right, a->causal)) return RFA_ERR_ARGS;
   if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v)) return RFA_ERR_ALIGN;
   if (!stride_ok(a->q_st, 2) || !stride_ok(a->k_st, 2) || !stride_ok(a->v_st, 2)) return RFA_ERR_ALIGN;
   if (a->out_acc) {
@@ -89,6 +102,10 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.wl = (a->window && a->window_left >= 0) ? a->window_left : -1;
   p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
+  p.drop_keep = drop_threshold(a->dropout_p);
+  p.drop_scale = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_seed = a->dropout_seed;
+  p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   const int rows = fwd_qrows_per_block();
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
   return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
@@ -133,7 +150,7 @@ struct DkdvPlan { int wide, nsplit; };
 static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   DkdvPlan pl{0, 1};
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-  if (a->dkdv_form == RFA_DKDV_128 || a->D != kHeadDim || win) return pl;
+  if (a->dkdv_form == RFA_DKDV_128 || a->D != kHeadDim || win || a->dropout_p > 0.f) return pl;
   const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
   // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) key blocks per K/V head, of which
   // only about total_k / 256 (+ one tail per sequence) are not past the end of their sequence
@@ -160,7 +177,7 @@ static bool bwd_needs_ws(const rfa_bwd_args* a) {
 
 static bool bwd_spill_eligible(const rfa_bwd_args* a) {
   return (a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && a->D == kHeadDim &&
-         a->B > 0 && a->Sq > 0 && a->Sk > 0 &&
+         a->B > 0 && a->Sq > 0 && a->Sk > 0 && !(a->dropout_p > 0.f) &&
          !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
 }
 
@@ -208,6 +225,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   if (!a->dk_acc && (!a->dk || !a->dv)) return RFA_ERR_NULL;
   if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
   if (a->dkdv_form < RFA_DKDV_AUTO || a->dkdv_form > RFA_DKDV_256 || a->dkdv_nsplit < 0) return RFA_ERR_ARGS;
+  if (!drop_args_ok(a->dropout_p, a->window, a->window_left, a->window_right, a->causal)) return RFA_ERR_ARGS;
   const bool ws = bwd_needs_ws(a);
   if (ws && !a->workspace) return RFA_ERR_NULL;
   if (!aligned16(a->dout) || !aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v))
@@ -237,6 +255,10 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.wl = (a->window && a->window_left >= 0) ? a->window_left : -1;
   p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
+  p.drop_keep = drop_threshold(a->dropout_p);
+  p.drop_scale = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_seed = a->dropout_seed;
+  p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();
   const DkdvPlan plan = bwd_dkdv_plan(a);
   p.wide = plan.wide; p.nsplit = plan.nsplit;

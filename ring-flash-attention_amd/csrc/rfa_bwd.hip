@@ -79,7 +79,8 @@ constexpr int kDqKV = 64;
 template <int kD> constexpr int dq_smem() { return 4 * kDqKV * kD * 2; }   // K[2] V[2]
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging), else zero padded (register staging)
-template <typename T, int kD, bool kFullD, bool kWin>
+// kDrop: dropout (the forward's mask, rfa_common.hpp: drop_word) applied to dP; instances without a window only
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
 __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -226,6 +227,9 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
         pin_vgpr(toff[dblk][kv][hh]);
       }
 
+  const uint32_t drop_key = kDrop ? drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)h) : 0u;
+  const uint32_t drop_i = kDrop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) + (uint32_t)qrow : 0u;
+  const uint32_t drop_j0 = kDrop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
   f32x16 dq[kNB];
 #pragma unroll
@@ -292,6 +296,19 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + 32 * t + crow(r, g);
             s[r] = (key > lim || (kWin && key < lim_lo)) ? 0.f : s[r];
+          }
+        }
+        if (kDrop) {
+          // dP = mask ∘ (dO V^T) / (1 - p): the gradient of the DROPPED probabilities; dS = P ∘ (dP - delta) keeps the
+          // undropped P (a dropped element still contributes -P delta)
+          const int mis = __builtin_amdgcn_readfirstlane((int)(drop_j0 & 3u));
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) {
+            const uint32_t jg = drop_j0 + (uint32_t)(kt0 + 32 * t + 8 * mm + 4 * g);
+            uint32_t w = drop_word(drop_key, drop_i, jg >> 2);
+            if (mis) w = __builtin_amdgcn_alignbyte(drop_word(drop_key, drop_i, (jg >> 2) + 1), w, (uint32_t)mis);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[4 * mm + e] = drop_keep(w, e, p.drop_keep) ? dp[4 * mm + e] * p.drop_scale : 0.f;
           }
         }
 #pragma unroll
@@ -381,12 +398,14 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 // one barrier per 128 MFMAs per SIMD instead of 64, no exchange at the end.  256-key workgroups are too few for
 // a causal launch at Hk = 8, so the tile range of a key block can be split over p.nsplit workgroups whose
 // partials (fp32, workspace) are summed by reduce_kernel (rfa_api.cpp).
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide>
+// kDrop: dropout — dV takes the dropped, rescaled probabilities, dS the masked dP (128-key form without spill / window)
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide, bool kDrop = false>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   static_assert(!kSpill || (kD == 128 && !kWin), "the dS spill path: head dim 128, no window");
   static_assert(!kWide || (kD == 128 && kFullD && !kWin), "the 256-key form: head dim 128, no window");
+  static_assert(!kDrop || (!kSpill && !kWin && !kWide), "dropout: the plain 128-key instances");
   constexpr int kKeys = kWide ? 2 * kKvKeys : kKvKeys;       // keys per workgroup
   typedef HeadGeo<kD> Geo;
   constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
@@ -614,6 +633,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kKeys / 32) + kbw);
 
+  // dropout: this lane's key position; the mask word of (query i, key j) is word(i, j >> 2), byte j & 3
+  const uint32_t drop_j = kDrop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) + (uint32_t)krow : 0u;
+  const uint32_t drop_i0 = kDrop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
   f32x16 dk[kNB], dv[kNB];
 #pragma unroll
@@ -716,11 +738,30 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
           s[r] = ok ? s[r] : 0.f;
         }
       }
+      if (kDrop) {
+        // dp holds dO V^T - delta (it was initialised with -delta).  With dropout
+        //     dP = keep ? (dO V^T) / (1 - p) : 0,   dS = P (dP - delta),   dV takes keep ? P / (1 - p) : 0
+        const uint32_t hkey = drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)(h0 + cg));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 nd = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kKvQ + 8 * jj) * 4);   // -delta
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * jj + e;
+            const uint32_t w = drop_word(hkey, drop_i0 + (uint32_t)(qs0 + crow(r, g)), drop_j >> 2);
+            const bool keep = drop_keep(w, (int)(drop_j & 3u), p.drop_keep);
+            const float dpd = keep ? (dp[r] - nd[e]) * p.drop_scale + nd[e] : nd[e];
+            dp[r] = dpd * s[r];
+            s[r] = keep ? s[r] * p.drop_scale : 0.f;
+          }
+        }
+      } else {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (RFA_KV_X_VALU) dp[4 * jj + e] *= s[4 * jj + e];
+      }
       {
         const vec8<T> pb0 = pack8<T>(s, 0), pb1 = pack8<T>(s, 8);
         const vec8<T> ds0 = pack8<T>(dp, 0), ds1 = pack8<T>(dp, 8);
@@ -864,47 +905,50 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   }
 }
 
-template <typename T, int kD, bool kFullD, bool kWin>
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
 static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kD, kFullD, kWin>, dq_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dq_kernel<T, kD, kFullD, kWin, kDrop>, dq_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dq_kernel<T, kD, kFullD, kWin>), dim3((unsigned)nblocks), dim3(kDqThreads), dq_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((dq_kernel<T, kD, kFullD, kWin, kDrop>), dim3((unsigned)nblocks), dim3(kDqThreads), dq_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false>
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false, bool kDrop = false>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide>, kv_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop>, kv_smem<kD>(), attr_done)) return rc;
   // one workgroup per (key block, K/V head) [x tile-range split of the 256-key form]
   const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B * (kWide ? p.nsplit : 1);
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, bool kWin>
+template <typename T, bool kWin, bool kDrop>
 static int launch_dq_d(const BwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return launch_dq_t<T, 128, true, kWin>(p, stream);
-  if (p.D > 64) return launch_dq_t<T, 128, false, kWin>(p, stream);
-  if (p.D == 64) return launch_dq_t<T, 64, true, kWin>(p, stream);
-  return launch_dq_t<T, 64, false, kWin>(p, stream);
+  if (p.D == 128) return launch_dq_t<T, 128, true, kWin, kDrop>(p, stream);
+  if (p.D > 64) return launch_dq_t<T, 128, false, kWin, kDrop>(p, stream);
+  if (p.D == 64) return launch_dq_t<T, 64, true, kWin, kDrop>(p, stream);
+  return launch_dq_t<T, 64, false, kWin, kDrop>(p, stream);
 }
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
-  if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_dq_d<bf16_t, true>(p, stream) : launch_dq_d<f16_t, true>(p, stream);
-  return dtype == 0 ? launch_dq_d<bf16_t, false>(p, stream) : launch_dq_d<f16_t, false>(p, stream);
+  if (p.drop_keep < 256) return dtype == 0 ? launch_dq_d<bf16_t, false, true>(p, stream) : launch_dq_d<f16_t, false, true>(p, stream);
+  if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_dq_d<bf16_t, true, false>(p, stream) : launch_dq_d<f16_t, true, false>(p, stream);
+  return dtype == 0 ? launch_dq_d<bf16_t, false, false>(p, stream) : launch_dq_d<f16_t, false, false>(p, stream);
 }
-template <typename T, bool kWin>
+template <typename T, bool kWin, bool kDrop>
 static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return launch_dkdv_t<T, 128, true, false, kWin>(p, stream);
-  if (p.D > 64) return launch_dkdv_t<T, 128, false, false, kWin>(p, stream);
-  if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin>(p, stream);
-  return launch_dkdv_t<T, 64, false, false, kWin>(p, stream);
+  if (p.D == 128) return launch_dkdv_t<T, 128, true, false, kWin, false, kDrop>(p, stream);
+  if (p.D > 64) return launch_dkdv_t<T, 128, false, false, kWin, false, kDrop>(p, stream);
+  if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin, false, kDrop>(p, stream);
+  return launch_dkdv_t<T, 64, false, false, kWin, false, kDrop>(p, stream);
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
+  if (p.drop_keep < 256)                          // rfa_api.cpp: dropout calls run the 128-key form without spill / window
+    return dtype == 0 ? launch_dkdv_d<bf16_t, false, true>(p, stream) : launch_dkdv_d<f16_t, false, true>(p, stream);
   if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 without a window
     if (p.ds != nullptr)
       return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true>(p, stream)
@@ -915,8 +959,8 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   if (p.ds != nullptr && p.D == 128 && !win)      // dS spill instance (rfa_api.cpp only passes ds for eligible calls)
     return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false>(p, stream)
                       : launch_dkdv_t<f16_t, 128, true, true, false>(p, stream);
-  if (win) return dtype == 0 ? launch_dkdv_d<bf16_t, true>(p, stream) : launch_dkdv_d<f16_t, true>(p, stream);
-  return dtype == 0 ? launch_dkdv_d<bf16_t, false>(p, stream) : launch_dkdv_d<f16_t, false>(p, stream);
+  if (win) return dtype == 0 ? launch_dkdv_d<bf16_t, true, false>(p, stream) : launch_dkdv_d<f16_t, true, false>(p, stream);
+  return dtype == 0 ? launch_dkdv_d<bf16_t, false, false>(p, stream) : launch_dkdv_d<f16_t, false, false>(p, stream);
 }
 int bwd_dq_rows_per_block() { return kDqRows; }
 int bwd_dkdv_keys_per_block(bool wide) { return wide ? 2 * kKvKeys : kKvKeys; }

@@ -289,6 +289,29 @@ __device__ __forceinline__ float buffer_load32(buf_rsrc_t r, int voffset) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voffset, 0, 0));
 }
 
+// ---- dropout: counter-based keep mask --------------------------------------------------------------------
+// The mask is a pure function of (seed, head, query position, key position) — NOT of the tiling, the kernel or the
+// rank that evaluates it — so the forward, both backward kernels, the CPU oracle (oracle/flash_attn_ref.py:
+// dropout_keep) and every rank of a sharded call see the same bits:
+//     word(i, jq) = fmix32( (i * 0x9E3779B1) ^ (jq * 0x85EBCA77) ^ head_key ),   jq = j >> 2
+//     element (i, j) is KEPT iff byte (j & 3) of word(i, j >> 2) < keep            (keep = round((1-p) * 256))
+// with fmix32 the 32-bit finalizer of MurmurHash3 and head_key = drop_head_key(seed, batch, head) below.
+// A word serves 4 consecutive keys of one query: one hash per 4 elements where a lane owns a query row
+// (forward, dQ), one per element where it owns a key (dK/dV).
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t drop_head_key(uint64_t seed, uint32_t batch, uint32_t head) {
+  return fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32(head * 0x27D4EB2Fu ^ fmix32(batch + 0x165667B1u))));
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t head_key, uint32_t i, uint32_t jq) {
+  return fmix32((i * 0x9E3779B1u) ^ (jq * 0x85EBCA77u) ^ head_key);
+}
+__device__ __forceinline__ bool drop_keep(uint32_t word, int byte, uint32_t keep) {
+  return ((word >> (8 * byte)) & 0xffu) < keep;
+}
+
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -48,7 +48,8 @@ template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * kD
 
 // kD: compiled head dim (128 or 64: half the MFMAs, half the LDS bytes per tile); kFullD: D == kD (LDS-DMA
 // staging, no conditional loads), otherwise D < kD is zero padded through the register staging path
-template <typename T, int kD, bool kFullD, bool kWin>
+// kDrop: dropout on the probabilities that enter P·V (instances without a window only)
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
 __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -205,6 +206,10 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         pin_vgpr(voff[dblk][kv][hh]);
       }
 
+  // dropout: global positions of this lane's query row and of key 0 of the sequence (packed input: absolute rows)
+  const uint32_t drop_key = kDrop ? drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)h) : 0u;
+  const uint32_t drop_i = kDrop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) + (uint32_t)qrow : 0u;
+  const uint32_t drop_j0 = kDrop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
   float m = -INFINITY;
   float lsum = 0.f;
@@ -318,6 +323,23 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
           psum += pv;
         }
       lsum += psum;
+      if (kDrop) {
+        // the row sum (and lse) are those of the undropped softmax; only what enters P·V is masked.  A lane holds,
+        // per (t, mm), 4 consecutive keys of its row: one mask word, or the bytes of two when the sequence's
+        // first key position is not a multiple of 4 (wave-uniform)
+        const int mis = __builtin_amdgcn_readfirstlane((int)(drop_j0 & 3u));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) {
+            const uint32_t jg = drop_j0 + (uint32_t)(kt0 + 32 * t + 8 * mm + 4 * g);
+            uint32_t w = drop_word(drop_key, drop_i, jg >> 2);
+            if (mis) w = __builtin_amdgcn_alignbyte(drop_word(drop_key, drop_i, (jg >> 2) + 1), w, (uint32_t)mis);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!drop_keep(w, e, p.drop_keep)) s[t][4 * mm + e] = 0.f;
+          }
+      }
 
       // ---------------- O^T += V^T P^T ----------------
 #pragma unroll
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   if (qrow >= lq) return;
   const float l = lsum + shfl_xor32(lsum);
   const bool has = l > 0.f;
-  const float inv = has ? 1.f / l : 0.f;
+  const float inv = has ? (kDrop ? p.drop_scale : 1.f) / l : 0.f;      // kept probabilities are scaled by 1 / (1 - p)
   const float blse = has ? m * p.scale + __logf(l) : INFINITY;   // natural log
   const int64_t orow = qs.row0 + qrow;
 
@@ -415,27 +437,30 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   }
 }
 
-template <typename T, int kD, bool kFullD, bool kWin>
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
 static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin>, fwd_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin, kDrop>, fwd_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin, kDrop>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, bool kWin>
+template <typename T, bool kWin, bool kDrop>
 static int launch_fwd_d(const FwdParams& p, hipStream_t stream) {
-  if (p.D == 128) return launch_fwd_t<T, 128, true, kWin>(p, stream);
-  if (p.D > 64) return launch_fwd_t<T, 128, false, kWin>(p, stream);
-  if (p.D == 64) return launch_fwd_t<T, 64, true, kWin>(p, stream);
-  return launch_fwd_t<T, 64, false, kWin>(p, stream);
+  if (p.D == 128) return launch_fwd_t<T, 128, true, kWin, kDrop>(p, stream);
+  if (p.D > 64) return launch_fwd_t<T, 128, false, kWin, kDrop>(p, stream);
+  if (p.D == 64) return launch_fwd_t<T, 64, true, kWin, kDrop>(p, stream);
+  return launch_fwd_t<T, 64, false, kWin, kDrop>(p, stream);
 }
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
-  if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_fwd_d<bf16_t, true>(p, stream) : launch_fwd_d<f16_t, true>(p, stream);
-  return dtype == 0 ? launch_fwd_d<bf16_t, false>(p, stream) : launch_fwd_d<f16_t, false>(p, stream);
+  if (p.drop_keep < 256)                                       // (rfa_api.cpp rejects dropout together with a window)
+    return dtype == 0 ? launch_fwd_d<bf16_t, false, true>(p, stream) : launch_fwd_d<f16_t, false, true>(p, stream);
+  if (windowed(p.causal, p.wl, p.wr))
+    return dtype == 0 ? launch_fwd_d<bf16_t, true, false>(p, stream) : launch_fwd_d<f16_t, true, false>(p, stream);
+  return dtype == 0 ? launch_fwd_d<bf16_t, false, false>(p, stream) : launch_fwd_d<f16_t, false, false>(p, stream);
 }
 
 int fwd_qrows_per_block() { return kFwdQRows; }

@@ -47,6 +47,12 @@ struct FwdParams {
                        // (causal is folded in by the API layer: wr = 0)
   int nqblk;
   float scale;
+  // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
+  // the offsets that turn local (head, query position, key position) into global ones
+  unsigned drop_keep;
+  float drop_scale;
+  unsigned long long drop_seed;
+  unsigned q_pos0, k_pos0, head0;
 };
 
 struct PreParams {
@@ -81,6 +87,12 @@ struct BwdParams {
   int wide, nsplit;
   int64_t kv_split_stride;
   int kv_part_f32;     // dk / dv point to fp32 PARTIALS in the workspace (split launches): fp32 stores, strides in fp32 elements
+  // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
+  // the offsets that turn local (head, query position, key position) into global ones
+  unsigned drop_keep;
+  float drop_scale;
+  unsigned long long drop_seed;
+  unsigned q_pos0, k_pos0, head0;
 };
 
 // dst[b, row, hk, :] (=|+=) sum_g src[b, row, hk*G+g, :]

@@ -40,6 +40,8 @@ class FwdArgs(C.Structure):
         ("causal", C.c_int32),
         ("dtype", C.c_int32),
         ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+        ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
     ]
 
 
@@ -81,6 +83,8 @@ class BwdArgs(C.Structure):
         ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
         ("dkdv_form", C.c_int32), ("dkdv_nsplit", C.c_int32),
         ("prof_events", C.POINTER(C.c_void_p)),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+        ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
     ]
 
 

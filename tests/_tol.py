@@ -5,9 +5,11 @@ N(0,1) inputs) must satisfy ALL of
 
   1. the non-finite pattern is identical (lse = +inf for rows without a visible key);
   2. max |err|        <= atol + rtol * max|ref|              (catches a single wrong element)
-  3. ||err||_F/||ref||_F <= fro                              (catches a systematic error where |ref| is small
+  3. ||err||_F <= fro * ||ref||_F + floor                    (catches a systematic error where |ref| is small
                                                               — late rows of a long causal sequence — which
-                                                              criterion 2 cannot see: SURVEY section 8(c))
+                                                              criterion 2 cannot see: SURVEY section 8(c); the
+                                                              floor, atol/4 per element, only matters when the
+                                                              reference itself is numerically zero)
   4. mean |err|       <= mean_abs + mean_rel * mean|ref|     (1e-3 for out)
 
 and `within_2x_naive(...)` states the criterion flash_attn's own tests use for their kernels and the reference's
@@ -21,19 +23,25 @@ import os
 
 import torch
 
-#            atol    rtol    fro     mean_abs  mean_rel
+#            atol    rtol     fro     mean_abs  mean_rel
+# Observed on MI355X (profiles/r03_tolerances_observed.txt, 1684 comparisons of the GPU suite), worst case per kind ->
+# bound: out max|err|/max|ref| 6.4e-3, fro 2.5e-3, mean/mean 2.0e-3; grad 7.8e-3, 3.0e-3, 2.3e-3; out_ring 6.9e-3,
+# 3.2e-3, 2.3e-3; grad_ring 1.04e-2, 4.5e-3, 3.4e-3; lse 1.9e-6 absolute.
 KINDS = {
     # oracle and kernel both round out to the io dtype: one ulp of the largest element + accumulated fp32 noise
-    "out":  (4e-3,  8e-3,   6e-3,   2e-4,     4e-3),
-    "lse":  (1e-4,  1e-5,   1e-5,   1e-5,     1e-6),
-    # gradients: sums over up to S terms, rounded to the io dtype once (twice across ring steps: see "grad_ring")
-    "grad": (4e-3,  8e-3,   8e-3,   3e-4,     6e-3),
+    "out":  (4e-3,  1.2e-2,  6e-3,   2e-4,     5e-3),
+    "lse":  (2e-5,  2e-6,    1e-6,   5e-6,     5e-7),
+    # gradients: sums over up to S terms, rounded to the io dtype once (more often across ring steps: "grad_ring")
+    "grad": (4e-3,  1.6e-2,  8e-3,   3e-4,     6e-3),
     # schedules over several ranks: block results are rounded to the io dtype at different points than in the
     # reference (fused fp32 merge vs bf16 block outputs): a few ulp of the largest element
-    "out_ring":  (8e-3, 1.2e-2, 8e-3,  3e-4, 6e-3),
-    "lse_ring":  (2e-4, 1e-4,   2e-5,  2e-5, 1e-6),
-    "grad_ring": (8e-3, 1.6e-2, 1.2e-2, 5e-4, 8e-3),
+    "out_ring":  (8e-3, 1.6e-2, 8e-3,   3e-4, 6e-3),
+    "lse_ring":  (5e-5, 5e-6,   2e-6,   1e-5, 1e-6),
+    "grad_ring": (8e-3, 2.4e-2, 1.2e-2, 5e-4, 8e-3),
 }
+# the Frobenius criterion is relative; a reference that is (numerically) zero — a query that sees a single key has
+# dQ = 0 exactly — is covered by this absolute floor per element, as a fraction of the kind's atol
+FRO_FLOOR = 0.25
 
 
 def metrics(got, ref):
@@ -41,12 +49,13 @@ def metrics(got, ref):
     fin = torch.isfinite(ref)
     same_pattern = bool(torch.equal(torch.isfinite(got), fin))
     if not fin.any():
-        return dict(same_pattern=same_pattern, max_err=0.0, max_ref=0.0, fro=0.0, mean_err=0.0, mean_ref=0.0, n=0)
+        return dict(same_pattern=same_pattern, max_err=0.0, max_ref=0.0, fro=0.0, err_norm=0.0, ref_norm=0.0,
+                    mean_err=0.0, mean_ref=0.0, n=0)
     g, r = got[fin].double(), ref[fin].double()
     e = (g - r).abs()
     nr = r.norm().item()
     return dict(same_pattern=same_pattern, max_err=e.max().item(), max_ref=r.abs().max().item(),
-                fro=(e.norm().item() / nr) if nr > 0 else e.norm().item(),
+                fro=(e.norm().item() / nr) if nr > 0 else float("inf"), err_norm=e.norm().item(), ref_norm=nr,
                 mean_err=e.mean().item(), mean_ref=r.abs().mean().item(), n=int(fin.sum()))
 
 
@@ -75,8 +84,10 @@ def failures(name, got, ref, kind, scale=1.0):
     lim = atol + rtol * m["max_ref"]
     if not m["max_err"] <= lim:
         bad.append(f"{name}: max|err| {m['max_err']:.3e} > {lim:.3e}")
-    if not m["fro"] <= fro:
-        bad.append(f"{name}: relative Frobenius error {m['fro']:.3e} > {fro:.1e}")
+    lim = fro * m["ref_norm"] + FRO_FLOOR * atol * m["n"] ** 0.5
+    if not m["err_norm"] <= lim:
+        bad.append(f"{name}: ||err||_F {m['err_norm']:.3e} > {fro:.1e} ||ref||_F + floor = {lim:.3e} "
+                   f"(relative Frobenius error {m['fro']:.3e})")
     lim = mabs + mrel * m["mean_ref"]
     if not m["mean_err"] <= lim:
         bad.append(f"{name}: mean|err| {m['mean_err']:.3e} > {lim:.3e}")

@@ -28,7 +28,10 @@ def _row(name, i, h, got, ref):
     if path:
         with open(path, "a") as f:
             f.write(f"row        rel-norm {rel:.3e} max_err {mx:.3e} max_ref {ref.abs().max().item():.3e}  headline.{name}[{i},{h}]\n")
-    assert rel <= 1e-2, f"{name}[{i},{h}]: relative error of the row {rel:.3e} > 1e-2"
+    # (observed on MI355X: <= 2.7e-3; a row whose exact value is zero — dq of a query that sees one key — is held to
+    #  the absolute floor instead)
+    assert err.norm().item() <= 1e-2 * ref.norm().item() + 5e-4 * ref.numel() ** 0.5, \
+        f"{name}[{i},{h}]: relative error of the row {rel:.3e} > 1e-2"
     assert mx <= 2e-3 + 1.6e-2 * ref.abs().max().item(), f"{name}[{i},{h}]: max|err| {mx:.3e}"
 
 
