@@ -74,8 +74,63 @@ def _mask(sq0: int, nq: int, lq: int, lk: int, causal: bool, device, window=None
     return m
 
 
-def _fwd_one(q, k, v, scale, causal, window=None):
-    """q (Lq,H,D), k,v (Lk,Hk,D) -> out fp32 (Lq,H,D), lse fp32 (H,Lq)."""
+# --------------------------------------------------------------------------------------------
+# Dropout.  flash_attn's own mask comes from its private Philox stream and cannot be reproduced without the
+# package; what CAN be stated exactly is the mask THIS library defines (include/rfa.h: rfa_fwd_args.dropout_p,
+# csrc/rfa_common.hpp: drop_word): a pure function of (seed, batch, head, query position, key position)
+#     word(i, jq) = fmix32((i * 0x9E3779B1) ^ (jq * 0x85EBCA77) ^ head_key),  jq = j >> 2
+#     keep(i, j)  = byte (j & 3) of word(i, j >> 2)  <  round((1 - p) * 256)
+# restated here with numpy uint32 arithmetic.  Semantics are flash_attn's: probabilities entering P V are masked and
+# scaled by 1 / (1 - p), lse is that of the undropped softmax, dP = mask * (dO V^T) / (1 - p), dS = P (dP - delta).
+# --------------------------------------------------------------------------------------------
+def _fmix32(x):
+    import numpy as np
+
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    x ^= x >> np.uint32(13)
+    x = (x * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def drop_threshold(p: float) -> int:
+    """keep threshold in 1/256 (rfa_api.cpp: drop_threshold)"""
+    if not p > 0:
+        return 256
+    return max(0, min(255, int((1.0 - float(torch.tensor(p, dtype=torch.float32))) * 256.0 + 0.5)))
+
+
+def dropout_keep(seed: int, p: float, batch: int, heads, i_pos, j_pos) -> torch.Tensor:
+    """bool (len(heads), len(i_pos), len(j_pos)): True where the probability of (head, query position, key
+    position) is kept.  heads / i_pos / j_pos: 1-D integer sequences of GLOBAL indices."""
+    import numpy as np
+
+    with np.errstate(over="ignore"):
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        h = np.asarray(list(heads), dtype=np.uint32)
+        hk = _fmix32(np.uint32(seed & 0xFFFFFFFF) ^ _fmix32(np.uint32(seed >> 32) ^ _fmix32(
+            (h * np.uint32(0x27D4EB2F)).astype(np.uint32) ^ _fmix32(np.asarray([(batch + 0x165667B1) & 0xFFFFFFFF], dtype=np.uint32)))))
+        i = np.asarray(i_pos, dtype=np.int64).astype(np.uint32)
+        j = np.asarray(j_pos, dtype=np.int64).astype(np.uint32)
+        a = (i * np.uint32(0x9E3779B1)).astype(np.uint32)[None, :, None]
+        b = ((j >> np.uint32(2)) * np.uint32(0x85EBCA77)).astype(np.uint32)[None, None, :]
+        w = _fmix32(a ^ b ^ hk[:, None, None])
+        byte = (w >> (np.uint32(8) * (j & np.uint32(3)))[None, None, :]) & np.uint32(0xFF)
+        keep = byte < np.uint32(drop_threshold(p))
+    return torch.from_numpy(keep)
+
+
+def _drop_mask(drop, H, s0, n, Lk):
+    """drop = dict(p, seed, batch, head0, q_pos0, k_pos0) -> keep (H, n, Lk) for query rows s0 .. s0+n-1"""
+    return dropout_keep(drop["seed"], drop["p"], drop.get("batch", 0), range(drop.get("head0", 0), drop.get("head0", 0) + H),
+                        range(drop.get("q_pos0", 0) + s0, drop.get("q_pos0", 0) + s0 + n),
+                        range(drop.get("k_pos0", 0), drop.get("k_pos0", 0) + Lk))
+
+
+def _fwd_one(q, k, v, scale, causal, window=None, drop=None):
+    """q (Lq,H,D), k,v (Lk,Hk,D) -> out fp32 (Lq,H,D), lse fp32 (H,Lq).  drop: see _drop_mask."""
     Lq, H, D = q.shape
     Lk, Hk, _ = k.shape
     G = H // Hk
@@ -96,12 +151,14 @@ def _fwd_one(q, k, v, scale, causal, window=None):
         p = torch.exp(s - l.unsqueeze(-1))
         empty = torch.isinf(l) & (l < 0)
         p = torch.where(empty.unsqueeze(-1), torch.zeros_like(p), p)
+        if drop is not None and drop["p"] > 0:
+            p = torch.where(_drop_mask(drop, H, s0, n, Lk), p / (1.0 - drop["p"]), torch.zeros_like(p))
         out[:, s0:s0 + n] = torch.matmul(p, vf)
         lse[:, s0:s0 + n] = torch.where(empty, torch.full_like(l, float("inf")), l)
     return out.permute(1, 0, 2), lse
 
 
-def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None, window=None):
+def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None, window=None, drop=None):
     """returns fp32 dq (Lq,H,D), dk, dv (Lk,Hk,D).  lse (H,Lq); delta (H,Lq) overrides rowsum(dO*O)."""
     Lq, H, D = q.shape
     Lk, Hk, _ = k.shape
@@ -124,17 +181,39 @@ def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None, window=None):
             if m is not None:
                 p = torch.where(m, p, torch.zeros_like(p))
             dp = torch.matmul(dof[:, s0:s0 + n], vf.transpose(1, 2))
+            pd = p
+            if drop is not None and drop["p"] > 0:
+                keep = _drop_mask(drop, H, s0, n, Lk)
+                rp = 1.0 / (1.0 - drop["p"])
+                dp = torch.where(keep, dp * rp, torch.zeros_like(dp))
+                pd = torch.where(keep, p * rp, torch.zeros_like(p))
             ds = p * (dp - delta[:, s0:s0 + n].unsqueeze(-1)) * scale
             dq[:, s0:s0 + n] = torch.matmul(ds, kf)
             dk += torch.matmul(ds.transpose(1, 2), qf[:, s0:s0 + n])
-            dv += torch.matmul(p.transpose(1, 2), dof[:, s0:s0 + n])
+            dv += torch.matmul(pd.transpose(1, 2), dof[:, s0:s0 + n])
     dk = dk.view(Hk, G, Lk, D).sum(1)
     dv = dv.view(Hk, G, Lk, D).sum(1)
     return dq.permute(1, 0, 2), dk.permute(1, 0, 2), dv.permute(1, 0, 2)
 
 
+def _new_rng_state():
+    """(seed, offset) like flash_attn's rng_state, drawn from torch's default CPU generator"""
+    return torch.tensor([int(torch.randint(0, 2 ** 62, (1,)).item()), 0], dtype=torch.int64)
+
+
+def _drop(dropout_p, rng_state, **pos):
+    if not dropout_p:
+        return None
+    assert rng_state is not None, "oracle: the backward of a dropout call needs the forward's rng_state"
+    return dict(p=float(dropout_p), seed=int(rng_state[0]), **pos)
+
+
 def _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes):
-    assert not dropout_p, "oracle: dropout is not restated (the reference path uses dropout_p=0)"
+    if dropout_p:
+        if not 0 <= dropout_p < 1:
+            raise ValueError("dropout_p must be in [0, 1)")
+        if window_size_left >= 0 or window_size_right >= 0:
+            raise NotImplementedError("dropout together with a window is not restated (nor implemented by the kernels)")
     assert not softcap, "oracle: softcap not restated"
     assert alibi_slopes is None, "oracle: alibi not restated"
 
@@ -151,18 +230,24 @@ def _flash_attn_forward(
     softcap: float = 0.0,
     alibi_slopes: Optional[torch.Tensor] = None,
     return_softmax: bool = False,
+    *,
+    rng_state: Optional[torch.Tensor] = None,
 ):
-    """q (B,Sq,H,D), k/v (B,Sk,Hk,D) -> (out (B,Sq,H,D) q.dtype, lse (B,H,Sq) fp32, None, None)."""
+    """q (B,Sq,H,D), k/v (B,Sk,Hk,D) -> (out (B,Sq,H,D) q.dtype, lse (B,H,Sq) fp32, None, rng_state).
+    rng_state (beyond flash_attn's signature): fix the dropout seed instead of drawing one."""
     _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
     B = q.shape[0]
     outs, lses = [], []
+    if dropout_p and rng_state is None:
+        rng_state = _new_rng_state()
     for b in range(B):
-        o, l = _fwd_one(q[b], k[b], v[b], softmax_scale, causal, (window_size_left, window_size_right))
+        o, l = _fwd_one(q[b], k[b], v[b], softmax_scale, causal, (window_size_left, window_size_right),
+                        drop=_drop(dropout_p, rng_state, batch=b))
         outs.append(o)
         lses.append(l)
     out = torch.stack(outs).to(q.dtype)
     lse = torch.stack(lses)
-    return out, lse, None, None
+    return out, lse, None, (rng_state if dropout_p else None)
 
 
 def _flash_attn_backward(
@@ -192,7 +277,7 @@ def _flash_attn_backward(
     ds = []
     for b in range(B):
         gq, gk, gv = _bwd_one(dout[b], q[b], k[b], v[b], out[b], softmax_lse[b], softmax_scale, causal,
-                              window=(window_size_left, window_size_right))
+                              window=(window_size_left, window_size_right), drop=_drop(dropout_p, rng_state, batch=b))
         dq[b].copy_(gq.to(dq.dtype))
         dk[b].copy_(gk.to(dk.dtype))
         dv[b].copy_(gv.to(dv.dtype))
@@ -220,8 +305,11 @@ def _flash_attn_varlen_forward(
     leftpad_k: Optional[torch.Tensor] = None,
     seqused_k: Optional[torch.Tensor] = None,
     zero_tensors: bool = False,
+    *,
+    rng_state: Optional[torch.Tensor] = None,
 ):
-    """q (Tq,H,D), k/v (Tk,Hk,D) -> (out (Tq,H,D), lse (H,Tq) fp32, None, None)."""
+    """q (Tq,H,D), k/v (Tk,Hk,D) -> (out (Tq,H,D), lse (H,Tq) fp32, None, rng_state).  Dropout positions of packed
+    input are the absolute rows of the packed tensors (include/rfa.h)."""
     _check(dropout_p, window_size_left, window_size_right, softcap, alibi_slopes)
     assert block_table is None and leftpad_k is None and seqused_k is None
     Tq, H, D = q.shape
@@ -229,12 +317,14 @@ def _flash_attn_varlen_forward(
     lse = torch.zeros((H, Tq), dtype=torch.float32, device=q.device)
     cq = [int(x) for x in cu_seqlens_q.tolist()]
     ck = [int(x) for x in cu_seqlens_k.tolist()]
+    if dropout_p and rng_state is None:
+        rng_state = _new_rng_state()
     for i in range(len(cq) - 1):
         o, l = _fwd_one(q[cq[i]:cq[i + 1]], k[ck[i]:ck[i + 1]], v[ck[i]:ck[i + 1]], softmax_scale, causal,
-                        (window_size_left, window_size_right))
+                        (window_size_left, window_size_right), drop=_drop(dropout_p, rng_state, q_pos0=cq[i], k_pos0=ck[i]))
         out[cq[i]:cq[i + 1]] = o
         lse[:, cq[i]:cq[i + 1]] = l
-    return out.to(q.dtype), lse, None, None
+    return out.to(q.dtype), lse, None, (rng_state if dropout_p else None)
 
 
 def _flash_attn_varlen_backward(
@@ -269,7 +359,7 @@ def _flash_attn_varlen_backward(
         a, b = cq[i], cq[i + 1]
         c, d = ck[i], ck[i + 1]
         gq, gk, gv = _bwd_one(dout[a:b], q[a:b], k[c:d], v[c:d], out[a:b], softmax_lse[:, a:b], softmax_scale, causal,
-                              window=(window_size_left, window_size_right))
+                              window=(window_size_left, window_size_right), drop=_drop(dropout_p, rng_state, q_pos0=a, k_pos0=c))
         dq[a:b] = gq.to(dq.dtype)
         dk[c:d] = gk.to(dk.dtype)
         dv[c:d] = gv.to(dv.dtype)

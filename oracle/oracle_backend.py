@@ -47,16 +47,27 @@ def _lse_rows(t, b, s, l):          # (B,H,S) or (H,T) -> (H,l) view
     return t[b, :, s:s + l] if b is not None else t[:, s:s + l]
 
 
+def _drop(dropout, bq, qs, ks):
+    """HipBackend's dropout=(p, seed, q_pos_offset, k_pos_offset, head_offset) -> the oracle's position dict: dense
+    sequences hash (batch, row inside the sequence), packed ones the absolute packed row (include/rfa.h)"""
+    if dropout is None or not dropout[0] > 0:
+        return None
+    p, seed, q0, k0, h0 = dropout
+    if bq is not None:
+        return dict(p=float(p), seed=int(seed), batch=bq, head0=h0, q_pos0=q0 + qs, k_pos0=k0 + ks)
+    return dict(p=float(p), seed=int(seed), batch=0, head0=h0, q_pos0=q0 + qs, k_pos0=k0 + ks)
+
+
 class OracleBackend:
     name = "oracle"
 
     # ------------------------------------------------------------------ forward
     def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
             max_seqlen_q=None, max_seqlen_k=None, q_half=0, k_half=0, out=None, lse=None,
-            out_acc=None, lse_acc=None, acc_init=False, window=(-1, -1)):
+            out_acc=None, lse_acc=None, acc_init=False, window=(-1, -1), dropout=None):
         for (bq, qs, ql), (bk, ks, kl) in zip(_seqs(q, cu_seqlens_q, q_half), _seqs(k, cu_seqlens_k, k_half)):
             o, l = R._fwd_one(_rows(q, bq, qs, ql), _rows(k, bk, ks, kl), _rows(v, bk, ks, kl), softmax_scale, causal,
-                              window)
+                              window, drop=_drop(dropout, bq, qs, ks))
             o = o.to(q.dtype)                       # flash_attn returns out in the io dtype
             if out_acc is None:
                 _rows(out, bq, qs, ql).copy_(o)
@@ -88,7 +99,8 @@ class OracleBackend:
     def bwd(self, dout, q, k, v, lse, delta, *, softmax_scale, causal, cu_seqlens_q=None,
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=0, k_half=0,
             dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None, acc_init=False,
-            deterministic=False, phases=BWD_ALL, partials=None, ds_scratch=None, window=(-1, -1)):
+            deterministic=False, phases=BWD_ALL, partials=None, ds_scratch=None, window=(-1, -1), dropout=None,
+            prof_events=None):
         pairs = list(zip(_seqs(q, cu_seqlens_q, q_half), _seqs(k, cu_seqlens_k, k_half)))
         kv_init = acc_init or bool(phases & 16)          # RFA_BWD_KV_OVERWRITE (include/rfa.h)
         phases &= 3
@@ -97,7 +109,8 @@ class OracleBackend:
             for (bq, qs, ql), (bk, ks, kl) in pairs:
                 gq, gk, gv = R._bwd_one(_rows(dout, bq, qs, ql), _rows(q, bq, qs, ql), _rows(k, bk, ks, kl),
                                         _rows(v, bk, ks, kl), None, _lse_rows(lse, bq, qs, ql), softmax_scale,
-                                        causal, delta=_lse_rows(delta, bq, qs, ql), window=window)
+                                        causal, delta=_lse_rows(delta, bq, qs, ql), window=window,
+                                        drop=_drop(dropout, bq, qs, ks))
                 gq, gk, gv = gq.to(q.dtype), gk.to(q.dtype), gv.to(q.dtype)   # flash_attn rounds here
                 if dq_acc is not None:
                     t = _rows(dq_acc, bq, qs, ql)

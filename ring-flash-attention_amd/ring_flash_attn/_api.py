@@ -6,13 +6,14 @@ The generated callables keep the exact keyword surface of the reference package
     dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
     deterministic=False, return_attn_probs=False, group=None
 with the reference's semantics: softmax_scale None -> head_dim ** -0.5; alibi_slopes must be
-None; dropout_p / window_size are accepted but unsupported (reference README.md:158-159);
+None; dropout_p / window_size work wherever one kernel call sees all keys (single-rank groups, llama3) and raise
+on a multi-rank ring (unsupported there in the reference too, README.md:158-159);
 return_attn_probs=True -> (out, softmax_lse, None); `group=None` is the default process group;
 inputs are the caller's LOCAL shard.
 """
 import torch
 
-from ._common import _prep_qkv, _as_cu
+from ._common import _prep_qkv, _as_cu, draw_dropout_seed
 
 
 def _opaque(fn):
@@ -53,8 +54,9 @@ def _compilable(fn, lower):
     def public(*args, **kwargs):
         if torch.compiler.is_compiling():
             # `group` may be passed positionally: resolve it the way the call itself would
-            group = sig.bind(*args, **kwargs).arguments.get("group", None)
-            if _single_rank(group):
+            bound = sig.bind(*args, **kwargs).arguments
+            # (dropout draws a host-side seed per call: such calls run eagerly behind a graph break)
+            if _single_rank(bound.get("group", None)) and not bound.get("dropout_p", 0.0):
                 return lower(*args, **kwargs)
         return eager(*args, **kwargs)
 
@@ -62,17 +64,24 @@ def _compilable(fn, lower):
 
 
 def _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=False):
-    """dropout is not implemented (nor usable in the reference's ring schedules, README.md:158-159).  Sliding windows
-    are implemented in the kernels (flash_attn semantics) and usable wherever ONE kernel call sees all the keys a
-    query may attend to: every function on a single-rank group, and llama3_flash_attn_varlen_func on any group (it
-    gathers K/V) — the same coverage the reference gets from forwarding window_size to flash_attn.  The ring / zigzag
-    / stripe schedules over several ranks would apply the window per block, which is wrong: they raise."""
+    """Sliding windows and dropout are implemented in the kernels (flash_attn semantics; dropout: the counter-based
+    mask of include/rfa.h) and usable wherever ONE kernel call sees all the keys a query may attend to: every function
+    on a single-rank group, and llama3_flash_attn_varlen_func on any group (it gathers K/V) — the same coverage the
+    reference gets from forwarding window_size / dropout_p to flash_attn (llama3_flash_attn_varlen.py:131-147).  The
+    ring / zigzag / stripe schedules over several ranks would apply a window per block, which is wrong, and the
+    reference declares dropout unsupported there (README.md:158-159): they raise.  Both together are not available."""
     assert alibi_slopes is None
-    if dropout_p and dropout_p > 0:
-        raise NotImplementedError("ring_flash_attn: dropout is not supported (as in the reference)")
+    drop = bool(dropout_p) and dropout_p > 0
+    if drop and not 0 < dropout_p < 1:
+        raise ValueError("dropout_p must be in [0, 1)")
+    if drop and not windows_ok:
+        raise NotImplementedError("ring_flash_attn: dropout over a multi-rank ring is not supported (as in the "
+                                  "reference); use llama3_flash_attn_varlen_func or a single-rank group")
     if not windows_ok and has_window(window_size):
         raise NotImplementedError("ring_flash_attn: sliding window over a multi-rank ring is not supported (as in the "
                                   "reference); use llama3_flash_attn_varlen_func or a single-rank group")
+    if drop and has_window(window_size):
+        raise NotImplementedError("ring_flash_attn: dropout together with a sliding window is not supported")
 
 
 def has_window(window_size) -> bool:
@@ -123,6 +132,9 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
             keep, extra = _keep_list(ctx, forward_impl)
+            ctx.dropout = (dropout_p, draw_dropout_seed()) if dropout_p and dropout_p > 0 else (0.0, None)
+            if ctx.dropout[1] is not None:
+                extra["dropout_seed"] = ctx.dropout[1]
             out, softmax_lse = forward_impl(
                 group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
@@ -141,9 +153,11 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
         def backward(ctx, dout, *args):
             q, k, v, out, softmax_lse, *more = ctx.saved_tensors
             tensors_lead, extra = _split_kept(ctx, more)
+            if ctx.dropout[1] is not None:
+                extra["dropout_seed"] = ctx.dropout[1]
             dq, dk, dv = backward_impl(
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
-                softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
+                softmax_scale=ctx.softmax_scale, dropout_p=ctx.dropout[0], causal=ctx.causal,
                 window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic, **extra,
             )
             return (dq, dk, dv) + (None,) * (n_lead + 8)
@@ -180,6 +194,9 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 lead = (cu,) + tuple(lead[1:])
                 tensors_lead = (cu,)
             keep, extra = _keep_list(ctx, forward_impl)
+            ctx.dropout = (dropout_p, draw_dropout_seed()) if dropout_p and dropout_p > 0 else (0.0, None)
+            if ctx.dropout[1] is not None:
+                extra["dropout_seed"] = ctx.dropout[1]
             out, softmax_lse = forward_impl(
                 group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
@@ -206,9 +223,11 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 out_grads = tuple(views)
             else:
                 out_grads = (None, views[0], views[1])
+            if ctx.dropout[1] is not None:
+                extra["dropout_seed"] = ctx.dropout[1]
             dq, dk, dv = backward_impl(
                 ctx.group, dout, q, k, v, out, softmax_lse, *tensors_lead, *ctx.lead_rest,
-                softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal,
+                softmax_scale=ctx.softmax_scale, dropout_p=ctx.dropout[0], causal=ctx.causal,
                 window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic,
                 out_grads=out_grads, **extra,
             )

@@ -48,3 +48,20 @@ def _as_cu(cu_seqlens, device):
     if cu_seqlens.device != device:
         cu_seqlens = cu_seqlens.to(device)
     return cu_seqlens.contiguous()
+
+
+def dropout_arg(dropout_p, dropout_seed, q_pos_offset=0, k_pos_offset=0, head_offset=0):
+    """backend `dropout=` argument (p, seed, q_pos_offset, k_pos_offset, head_offset), or None when dropout is off.
+    The seed comes from the autograd Function (one draw per forward, reused by its backward)."""
+    if not dropout_p or not dropout_p > 0:
+        return None
+    if dropout_seed is None:
+        raise ValueError("ring_flash_attn: dropout_p > 0 needs a dropout_seed (the public functions draw one)")
+    return (float(dropout_p), int(dropout_seed), int(q_pos_offset), int(k_pos_offset), int(head_offset))
+
+
+def draw_dropout_seed() -> int:
+    """one 62-bit seed from torch's default CPU generator (reproducible under torch.manual_seed; ranks that seeded
+    alike draw alike, which makes the mask of a sharded call equal to the unsharded one — include/rfa.h)"""
+    import torch
+    return int(torch.randint(0, 2 ** 62, (1,)).item())

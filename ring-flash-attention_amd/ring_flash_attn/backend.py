@@ -79,9 +79,10 @@ class HipBackend:
     # ------------------------------------------------------------------ forward
     def fwd(self, q, k, v, *, softmax_scale, causal, cu_seqlens_q=None, cu_seqlens_k=None,
             max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL, k_half=HALF_FULL,
-            out=None, lse=None, out_acc=None, lse_acc=None, acc_init=False, window=(-1, -1)):
+            out=None, lse=None, out_acc=None, lse_acc=None, acc_init=False, window=(-1, -1), dropout=None):
         """Block attention.  Plain mode fills (out, lse); accumulate mode merges into the fp32
-        (out_acc, lse_acc) pair (fused update_out_and_lse).  Dense: q (B,Sq,H,D); varlen: (T,H,D)."""
+        (out_acc, lse_acc) pair (fused update_out_and_lse).  Dense: q (B,Sq,H,D); varlen: (T,H,D).
+        dropout: (p, seed, q_pos_offset, k_pos_offset, head_offset) or None."""
         self._check_dev(q, k, v, out, lse, out_acc, lse_acc)
         varlen = cu_seqlens_q is not None
         a = _C.FwdArgs()
@@ -111,6 +112,7 @@ class HipBackend:
         if window is not None and (window[0] >= 0 or window[1] >= 0):
             a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
+        _set_dropout(a, dropout)
         _C.check(self.lib.rfa_fwd(C.byref(a), _stream(q)), "rfa_fwd")
 
     # ------------------------------------------------------------------ backward
@@ -137,7 +139,7 @@ class HipBackend:
             cu_seqlens_k=None, max_seqlen_q=None, max_seqlen_k=None, q_half=HALF_FULL,
             k_half=HALF_FULL, dq=None, dk=None, dv=None, dq_acc=None, dk_acc=None, dv_acc=None,
             acc_init=False, deterministic=False, phases=_C.BWD_ALL, partials=None, ds_scratch=None,
-            window=(-1, -1), prof_events=None):
+            window=(-1, -1), prof_events=None, dropout=None):
         """dQ/dK/dV of one block.  Plain outputs (io dtype) or `+=` into fp32 accumulators.
         phases=BWD_COMPUTE / BWD_REDUCE splits the call so a ring step can overlap the kernels
         with the arrival of the dk/dv accumulators it adds into: the COMPUTE call RETURNS the buffer
@@ -185,6 +187,7 @@ class HipBackend:
             a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         a.phases = phases
+        _set_dropout(a, dropout)
         if prof_events is not None:       # measurement (bench.py): a ctypes array of 4 hipEvent_t, see include/rfa.h
             a.prof_events = prof_events
         reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
@@ -322,6 +325,15 @@ class HipBackend:
                                             int(max_seqlen), lse_packed.stride(1), lse_packed.stride(0),
                                             _stream(lse_packed)), "rfa_lse_unflatten")
         return dst
+
+
+def _set_dropout(a, dropout):
+    """dropout = (p, seed, q_pos_offset, k_pos_offset, head_offset) or None (include/rfa.h: rfa_fwd_args.dropout_p)"""
+    if dropout is None or not dropout[0] > 0:
+        return
+    p, seed, q0, k0, h0 = dropout
+    a.dropout_p, a.dropout_seed = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
+    a.q_pos_offset, a.k_pos_offset, a.head_offset = int(q0), int(k0), int(h0)
 
 
 def _spill_enabled() -> bool:

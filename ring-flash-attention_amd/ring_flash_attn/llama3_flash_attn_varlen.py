@@ -29,7 +29,7 @@ import torch
 from .backend import get_backend
 from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async, single_rank
 from ._api import _check_unsupported, _opaque
-from ._common import _as_cu
+from ._common import _as_cu, dropout_arg, draw_dropout_seed
 
 
 def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world: int, head_dim: int,
@@ -107,6 +107,7 @@ def llama3_flash_attn_varlen_forward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
 ):
     be = get_backend()
     T, nheads, head_dim = q.shape
@@ -117,11 +118,18 @@ def llama3_flash_attn_varlen_forward(
 
     out = torch.empty_like(q)
     lse = torch.empty((nheads, T), dtype=torch.float32, device=q.device)
-    world_size = group_rank_world(process_group)[1]
+    rank, world_size = group_rank_world(process_group)
+    # dropout positions are GLOBAL (stream position of a query = rank * T + local row; of a key = its row in the
+    # gathered stream; head = its index among all query heads), so every rank — and every head group — draws the bits
+    # an unsharded call with the same seed would (include/rfa.h)
+    k_lo = local_k_slice.start or 0
+
+    def drop(head0):
+        return dropout_arg(dropout_p, dropout_seed, rank * T, k_lo, head0)
 
     if single_rank(world_size):
         be.fwd(q, k[local_k_slice], v[local_k_slice], softmax_scale=softmax_scale, causal=causal,
-               out=out, lse=lse, window=window_size, **vl)
+               out=out, lse=lse, window=window_size, dropout=drop(0), **vl)
         return out, lse
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
@@ -145,7 +153,8 @@ def llama3_flash_attn_varlen_forward(
             pending = post_gather(gi + 1)          # next super-group's K/V arrive beside this one's attention
         q_slice = slice(g0 * nheads // nheads_k, (g0 + hs) * nheads // nheads_k)
         be.fwd(q[:, q_slice], buf[0][local_k_slice], buf[1][local_k_slice],
-               softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], window=window_size, **vl)
+               softmax_scale=softmax_scale, causal=causal, out=out[:, q_slice], lse=lse[q_slice], window=window_size,
+               dropout=drop(q_slice.start), **vl)
 
     return out, lse
 
@@ -170,6 +179,7 @@ def llama3_flash_attn_varlen_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
 ):
     be = get_backend()
     T, nheads, head_dim = q.shape
@@ -188,14 +198,19 @@ def llama3_flash_attn_varlen_backward(
     dq = torch.empty_like(q)
     dk = torch.empty_like(k)
     dv = torch.empty_like(v)
-    world_size = group_rank_world(process_group)[1]
+    rank, world_size = group_rank_world(process_group)
+    k_lo = local_k_slice.start or 0
+
+    def drop(head0):                       # (the forward's positions)
+        return dropout_arg(dropout_p, dropout_seed, rank * T, k_lo, head0)
 
     if single_rank(world_size):
         if local_k_slice.start != 0 or local_k_slice.stop != total_k:
             dk.zero_()
             dv.zero_()
         be.bwd(dout, q, k[local_k_slice], v[local_k_slice], softmax_lse, delta, softmax_scale=softmax_scale,
-               causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, window=window_size, **vl)
+               causal=causal, dq=dq, dk=dk[local_k_slice], dv=dv[local_k_slice], deterministic=deterministic, window=window_size,
+               dropout=drop(0), **vl)
         return dq, dk, dv
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
@@ -243,7 +258,7 @@ def llama3_flash_attn_varlen_backward(
         be.bwd(dout[:, q_slice], q[:, q_slice], kv[0][local_k_slice], kv[1][local_k_slice],
                softmax_lse[q_slice], delta[q_slice], softmax_scale=softmax_scale, causal=causal,
                dq=dq[:, q_slice], dk=dkv[0][local_k_slice], dv=dkv[1][local_k_slice],
-               deterministic=deterministic, window=window_size, **vl)
+               deterministic=deterministic, window=window_size, dropout=drop(q_slice.start), **vl)
         if job is not None:
             finish(job)                          # group gi-1's exchange ran beside the kernels just enqueued
         dst = (dk, dv) if whole else (rs_out[gi % 2][0], rs_out[gi % 2][1])
@@ -270,10 +285,11 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
         v = v.contiguous()
         cu_seqlens_q = _as_cu(cu_seqlens_q, q.device)
         cu_seqlens_k = _as_cu(cu_seqlens_k, q.device)
+        ctx.dropout = (dropout_p, draw_dropout_seed()) if dropout_p and dropout_p > 0 else (0.0, None)
         out, softmax_lse = llama3_flash_attn_varlen_forward(
             group, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
             local_k_slice, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
-            window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False,
+            window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, dropout_seed=ctx.dropout[1],
         )
         ctx.save_for_backward(q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k)
         ctx.static = (max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice)
@@ -289,8 +305,8 @@ class Llama3FlashAttnVarlenFunc(torch.autograd.Function):
         q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k = ctx.saved_tensors
         dq, dk, dv = llama3_flash_attn_varlen_backward(
             ctx.group, dout, q, k, v, out, softmax_lse, cu_seqlens_q, cu_seqlens_k, *ctx.static,
-            softmax_scale=ctx.softmax_scale, dropout_p=0.0, causal=ctx.causal, window_size=ctx.window_size,
-            alibi_slopes=None, deterministic=ctx.deterministic,
+            softmax_scale=ctx.softmax_scale, dropout_p=ctx.dropout[0], causal=ctx.causal, window_size=ctx.window_size,
+            alibi_slopes=None, deterministic=ctx.deterministic, dropout_seed=ctx.dropout[1],
         )
         return (dq, dk, dv) + (None,) * 15
 

@@ -12,6 +12,7 @@ import torch
 from . import _C
 from .backend import get_backend
 from .utils import RingComm, single_rank
+from ._common import dropout_arg
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 
 
@@ -26,6 +27,7 @@ def stripe_flash_attn_forward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
 ):
     assert (
         causal
@@ -37,8 +39,9 @@ def stripe_flash_attn_forward(
     if single_rank(comm.world_size):
         out = torch.empty_like(q)
         lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
-        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size, dropout=dropout_arg(dropout_p, dropout_seed))
         return out, lse
+    assert not dropout_p, "dropout over a multi-rank ring is not supported (as in the reference)"
 
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
@@ -75,6 +78,7 @@ def stripe_flash_attn_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
     out_grads=None,
 ):
     assert (
@@ -95,8 +99,9 @@ def stripe_flash_attn_backward(
     if single_rank(kv_comm.world_size):
         dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size)
+               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, dropout=dropout_arg(dropout_p, dropout_seed))
         return dq, dk, dv
+    assert not dropout_p, "dropout over a multi-rank ring is not supported (as in the reference)"
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)

@@ -129,6 +129,8 @@ class ZigZagLlama3FlashAttnVarlenFunc(torch.autograd.Function):
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=True)   # K/V are gathered
+        if dropout_p and dropout_p > 0:
+            raise NotImplementedError("zigzag_llama3_flash_attn_varlen_func: dropout is not supported")
         if q.shape[0] % 2 != 0 or k.shape[0] != q.shape[0] or v.shape[0] != q.shape[0]:
             raise ValueError("zigzag_llama3: q, k, v hold the two stream slices of this rank (an even number of rows)")
         if q.stride(-1) != 1:

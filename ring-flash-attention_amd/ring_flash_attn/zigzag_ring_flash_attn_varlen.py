@@ -26,6 +26,7 @@ import torch
 from . import _C
 from .backend import get_backend, HALF_FRONT, HALF_BACK
 from .utils import AllGatherComm, RingComm, all_to_all_async, single_rank
+from ._common import dropout_arg
 from ._api import make_autograd_function, make_varlen_api, _grad_buffers
 
 
@@ -94,6 +95,7 @@ def zigzag_ring_flash_attn_varlen_forward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
 ):
     assert causal == True, "zigzag ring is meaningless for causal=False"
     be = get_backend()
@@ -104,8 +106,9 @@ def zigzag_ring_flash_attn_varlen_forward(
     if single_rank(comm.world_size):
         out = torch.empty_like(q)
         lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
-        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size, **vl)
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True, out=out, lse=lse, window=window_size, dropout=dropout_arg(dropout_p, dropout_seed), **vl)
         return out, lse
+    assert not dropout_p, "dropout over a multi-rank ring is not supported (as in the reference)"
 
     out_acc = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((H, T), dtype=torch.float32, device=q.device)
@@ -161,6 +164,7 @@ def zigzag_ring_flash_attn_varlen_backward(
     window_size=(-1, -1),
     alibi_slopes=None,
     deterministic=False,
+    dropout_seed=None,
     out_grads=None,
 ):
     assert causal == True, "zigzag ring is meaningless for causal=False"
@@ -180,8 +184,9 @@ def zigzag_ring_flash_attn_varlen_backward(
     if single_rank(kv_comm.world_size):
         dq, dk, dv = _grad_buffers(out_grads, q, k, v)
         be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
-               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, **vl)
+               dq=dq, dk=dk, dv=dv, deterministic=deterministic, window=window_size, dropout=dropout_arg(dropout_p, dropout_seed), **vl)
         return dq, dk, dv
+    assert not dropout_p, "dropout over a multi-rank ring is not supported (as in the reference)"
 
     dq = torch.empty((T, H, D), dtype=torch.float32, device=q.device)
     dk = torch.empty(k.shape, dtype=torch.float32, device=q.device)

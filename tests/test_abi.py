@@ -188,10 +188,14 @@ def test_flash_attn_shim_surface(built):
     import torch
 
     q = torch.zeros(1, 8, 2, 64, dtype=torch.bfloat16)
-    with pytest.raises(NotImplementedError):
-        F._flash_attn_forward(q, q, q, 0.1, 0.125, True)
+    with pytest.raises(NotImplementedError):                       # dropout together with a window
+        F._flash_attn_forward(q, q, q, 0.1, 0.125, True, window_size_left=4)
     with pytest.raises(NotImplementedError):
         F._flash_attn_forward(q, q, q, 0.0, 0.125, True, softcap=30.0)
+    with pytest.raises(ValueError, match="rng_state"):            # a dropout backward without the forward's state
+        F._flash_attn_backward(q, q, q, q, q, None, q, q, q, 0.1, 0.125, True)
+    # (the forward's extra `rng_state` is keyword-only: flash_attn's positional signature is untouched)
+    assert "rng_state" in inspect.getfullargspec(F._flash_attn_forward).kwonlyargs
 
 
 def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):

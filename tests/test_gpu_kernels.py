@@ -547,3 +547,109 @@ def test_sliding_window_varlen_and_llama3_single_rank(single_rank_group):
     _check("out", out, ro, 0, kind="out")
     _check("lse", lse, rl, 0, kind="lse")
     _grads_ok("llama3 window", (qd.grad, kd.grad, vd.grad), (rdq, rdk, rdv))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# dropout (include/rfa.h: rfa_fwd_args.dropout_p): the kernels' mask against the oracle's restatement of it
+@pytest.mark.parametrize("D,H,Hk,Sq,Sk,causal,dtype", [
+    (128, 4, 2, 777, 777, True, BF),          # GQA, odd length (masked tails)
+    (128, 2, 2, 300, 555, True, BF),          # bottom-right aligned
+    (64, 4, 1, 512, 512, False, BF),          # head-dim-64 instances, no mask
+    (96, 2, 2, 260, 260, True, torch.float16),   # padded head dim (register staging), fp16
+])
+def test_dropout_dense_matches_oracle(D, H, Hk, Sq, Sk, causal, dtype):
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    g = torch.Generator().manual_seed(D + Sq)
+    B, p, seed = 2, 0.15, 0x0123_4567_89AB_CDEF
+    q, k, v = (torch.randn(B, s_, h_, D, generator=g).to(dtype) for s_, h_ in ((Sq, H), (Sk, Hk), (Sk, Hk)))
+    do = torch.randn(B, Sq, H, D, generator=g).to(dtype)
+    scale = D ** -0.5
+    rng = torch.tensor([seed, 0])
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, p, scale, causal, rng_state=rng)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, p, scale, causal, rng_state=rng)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out, lse = torch.empty_like(qd), torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    drop = (p, seed, 0, 0, 0)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse, dropout=drop)
+    _check("drop.out", out, ro, 0, kind="out")
+    _check("drop.lse", lse, rl, 0, kind="lse")
+    plain = torch.empty_like(qd)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=plain, lse=torch.empty_like(lse))
+    assert (plain.float() - out.float()).abs().max().item() > 0.05          # the mask did something
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv, dropout=drop)
+    _grads_ok("drop", (dq, dk, dv), (rdq, rdk, rdv))
+    # positions are global: rows [a, b) of the queries with q_pos_offset = a give rows [a, b) of the full result
+    if not causal:
+        a = 129
+        part = torch.empty_like(qd[:, a:])
+        be.fwd(qd[:, a:], kd, vd, softmax_scale=scale, causal=False, out=part, lse=torch.empty((B, H, Sq - a), dtype=torch.float32, device=dev),
+               dropout=(p, seed, a, 0, 0))
+        assert torch.equal(part, out[:, a:])
+
+
+@pytest.mark.parametrize("cu", [[0, 128, 1248, 2001], [0, 3, 70, 71, 600]])
+def test_dropout_varlen_public_api_matches_oracle(single_rank_group, cu):
+    """packed sequences starting at positions that are not multiples of 4 (the mask words then straddle the lanes' key
+    groups), through the public function (seed drawn from torch's generator) — forward and backward"""
+    import ring_flash_attn as R
+    from ring_flash_attn._common import draw_dropout_seed
+    from oracle import flash_attn_ref as O
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(len(cu))
+    T, H, Hk, D, p = cu[-1], 4, 2, 128, 0.1
+    q, k, v = (torch.randn(T, h_, D, generator=g).to(BF) for h_ in (H, Hk, Hk))
+    do = torch.randn(T, H, D, generator=g).to(BF)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    mx = max(b - a for a, b in zip(cu[:-1], cu[1:]))
+    torch.manual_seed(77)
+    rng = torch.tensor([draw_dropout_seed(), 0])
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu_t, cu_t, mx, mx, p, D ** -0.5, True, rng_state=rng)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, cu_t, cu_t, mx, mx, p, D ** -0.5, True, rng_state=rng)
+    qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    torch.manual_seed(77)
+    out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(qd, kd, vd, cu_t.to(dev), mx, dropout_p=p, causal=True,
+                                                       return_attn_probs=True)
+    out.backward(do.to(dev))
+    _check("drop.varlen.out", out, ro, 0, kind="out")
+    _check("drop.varlen.lse", lse, rl, 0, kind="lse")
+    _grads_ok("drop.varlen", (qd.grad, kd.grad, vd.grad), (rdq, rdk, rdv))
+
+
+@pytest.mark.parametrize("W,stride", [(2, 1), (4, 2)])
+def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
+    """llama3 over W ranks sharing the GPU, dropout on: every rank / head group draws the bits of the unsharded call"""
+    import torch.multiprocessing as mp
+    import _dropout_worker as DW
+    from conftest import free_port
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn._common import draw_dropout_seed
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(DW.run, args=(W, free_port(), ret, True, stride), nprocs=W, join=True)
+    q, k, v, do = DW.inputs()
+    torch.manual_seed(DW.SEED)
+    rng = torch.tensor([draw_dropout_seed(), 0])
+    cu = torch.tensor(DW.CU, dtype=torch.int32)
+    scale = DW.D ** -0.5
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, DW.P_DROP, scale, True, rng_state=rng)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, dq, dk, dv, cu, cu, 0, 0, DW.P_DROP, scale, True, rng_state=rng)
+    T = DW.CU[-1] // W
+    for r in range(W):
+        got = ret[r]
+        assert not isinstance(got, str), got
+        sl = slice(r * T, (r + 1) * T)
+        _check(f"r{r}.out", got["out"], ro[sl], 0, kind="out_ring")
+        for name, ref in (("dq", dq), ("dk", dk), ("dv", dv)):
+            _check(f"r{r}.{name}", got[name], ref[sl], 0, kind="grad_ring")

@@ -165,3 +165,69 @@ def test_oracle_sliding_window_vs_explicit_mask(Sq, Sk, causal, window):
                            window[0], window[1])
     for got, ref in ((dq, qd.grad), (dk, kd.grad), (dv, vd.grad)):
         assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# dropout: the mask is this library's own definition (include/rfa.h, csrc/rfa_common.hpp: drop_word), restated by
+# oracle/flash_attn_ref.py: dropout_keep; the arithmetic around it is flash_attn's.
+def _dropout_fp64(q, k, v, do, causal, p, keep):
+    """independent formulation: explicit keep mask (B,H,Sq,Sk) applied to the softmax, fp64 autograd"""
+    B, Sq, H, D = q.shape
+    Sk, Hk = k.shape[1], k.shape[2]
+    qd, kd, vd = [t.double().requires_grad_(True) for t in (q, k, v)]
+    s = torch.einsum("bqhd,bkhd->bhqk", qd, kd.repeat_interleave(H // Hk, dim=2)) * D ** -0.5
+    if causal:
+        i = torch.arange(Sq).view(-1, 1) + (Sk - Sq)
+        s = s.masked_fill(torch.arange(Sk).view(1, -1) > i, float("-inf"))
+    pr = torch.nan_to_num(torch.softmax(s, -1), nan=0.0)
+    out = torch.einsum("bhqk,bkhd->bqhd", torch.where(keep, pr / (1 - p), torch.zeros_like(pr)),
+                       vd.repeat_interleave(H // Hk, dim=2))
+    out.backward(do.double())
+    return out.detach(), qd.grad, kd.grad, vd.grad
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal", SHAPES[:3] + SHAPES[4:])
+def test_oracle_dropout_vs_fp64_autograd(B, Sq, Sk, H, Hk, D, causal):
+    q, k, v = _rand((B, Sq, H, D), 1), _rand((B, Sk, Hk, D), 2), _rand((B, Sk, Hk, D), 3)
+    do = _rand((B, Sq, H, D), 4)
+    p, scale = 0.17, D ** -0.5
+    rng = torch.tensor([0x1234_5678_9ABC_DEF, 0])
+    out, lse, _, rs = R._flash_attn_forward(q.float(), k.float(), v.float(), p, scale, causal, rng_state=rng)
+    lse0 = R._flash_attn_forward(q.float(), k.float(), v.float(), 0.0, scale, causal)[1]
+    assert torch.equal(rs, rng) and torch.equal(lse, lse0)        # lse is that of the undropped softmax
+    keep = torch.stack([R.dropout_keep(int(rng[0]), p, b, range(H), range(Sq), range(Sk)) for b in range(B)])
+    frac = keep.float().mean().item()
+    assert abs(frac - R.drop_threshold(p) / 256) < 0.02           # keep probability = round((1-p) 256) / 256
+    ro, rq, rk, rv = _dropout_fp64(q, k, v, do, causal, p, keep)
+    assert (out.double() - ro).abs().max() < 2e-5
+    dq, dk, dv = torch.empty_like(q, dtype=torch.float32), torch.empty_like(k, dtype=torch.float32), torch.empty_like(v, dtype=torch.float32)
+    R._flash_attn_backward(do.float(), q.float(), k.float(), v.float(), out, lse, dq, dk, dv, p, scale, causal, rng_state=rng)
+    for got, ref in ((dq, rq), (dk, rk), (dv, rv)):
+        assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_dropout_mask_definition():
+    """known-answer pins of the mask function (so that the C++ and the Python statement cannot drift together
+    unnoticed), its position semantics, and its statistics"""
+    # fmix32 is MurmurHash3's 32-bit finalizer: published test values
+    import numpy as np
+
+    assert [int(x) for x in R._fmix32(np.asarray([0, 1, 0xFFFFFFFF, 0x12345678], dtype=np.uint32))] == \
+        [0, 0x514E28B7, 0x81F16F39, 0xE37CD1BC]
+    a = R.dropout_keep(7, 0.5, 0, [3], range(10, 20), range(100, 164))
+    # a mask is a function of GLOBAL positions: any window of a larger mask equals the mask of that window
+    big = R.dropout_keep(7, 0.5, 0, [0, 3, 5], range(0, 32), range(64, 200))
+    assert torch.equal(a[0], big[1, 10:20, 36:100])
+    # different seed / head / batch -> different bits; same arguments -> same bits
+    assert torch.equal(a, R.dropout_keep(7, 0.5, 0, [3], range(10, 20), range(100, 164)))
+    for other in (R.dropout_keep(8, 0.5, 0, [3], range(10, 20), range(100, 164)),
+                  R.dropout_keep(7, 0.5, 0, [4], range(10, 20), range(100, 164)),
+                  R.dropout_keep(7, 0.5, 1, [3], range(10, 20), range(100, 164))):
+        assert 0.3 < (other != a).float().mean() < 0.7
+    # thresholds: p = 0 keeps everything, p -> 1 keeps (almost) nothing, keep rate = round((1 - p) 256) / 256
+    assert R.drop_threshold(0.0) == 256 and R.drop_threshold(0.1) == 230 and R.drop_threshold(0.999) == 0
+    m = R.dropout_keep(99, 0.1, 0, range(4), range(512), range(512)).float()
+    assert abs(m.mean().item() - 230 / 256) < 2e-3
+    # no visible structure along rows, keys or the 4-key word groups
+    assert m.mean(dim=(0, 2)).std() < 0.02 and m.mean(dim=(0, 1)).std() < 0.02
+    assert abs(m[..., 0::4].mean() - m[..., 3::4].mean()) < 5e-3

@@ -133,6 +133,80 @@ def test_exchange_autotune_is_a_collective_decision(break_gather):
             assert a["probe"][kind]["GBps"] > 0 and a["probe"][kind]["ms"] == b["probe"][kind]["ms"]
 
 
+@pytest.mark.parametrize("W,stride", [(2, 1), (4, 2)])
+def test_llama3_dropout_is_consistent_across_ranks(W, stride):
+    """dropout on the llama3 path (the one place the reference forwards dropout_p to flash_attn,
+    llama3_flash_attn_varlen.py:131,266): the mask is a function of GLOBAL (head, query position, key position), so W
+    ranks — each running its head groups one after the other — reproduce the single-device result with the same seed;
+    forward and backward use the same mask (gradients match); the ring schedules raise over several ranks."""
+    import torch
+    import torch.multiprocessing as mp
+    import _dropout_worker as DW
+    from oracle import flash_attn_ref as O
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(DW.run, args=(W, free_port(), ret, False, stride), nprocs=W, join=True)
+    q, k, v, do = DW.inputs()
+    torch.manual_seed(DW.SEED)
+    from ring_flash_attn._common import draw_dropout_seed
+
+    rng = torch.tensor([draw_dropout_seed(), 0])
+    cu = torch.tensor(DW.CU, dtype=torch.int32)
+    scale = DW.D ** -0.5
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, DW.P_DROP, scale, True, rng_state=rng)
+    r0 = O._flash_attn_varlen_forward(q, k, v, cu, cu, 0, 0, 0.0, scale, True)[0]
+    assert (ro.float() - r0.float()).abs().max() > 0.05            # dropout did something
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_varlen_backward(do, q, k, v, ro, rl, dq, dk, dv, cu, cu, 0, 0, DW.P_DROP, scale, True, rng_state=rng)
+    T = DW.CU[-1] // W
+    for r in range(W):
+        got = ret[r]
+        assert not isinstance(got, str), got
+        sl = slice(r * T, (r + 1) * T)
+        assert got["raised"] == [True, True, True]
+        assert (got["out"].float() - ro[sl].float()).abs().max() <= 2e-2
+        for name, ref in (("dq", dq), ("dk", dk), ("dv", dv)):
+            d = (got[name].float() - ref[sl].float()).abs().max().item()
+            assert d <= 3e-2 + 1e-2 * ref.float().abs().max().item(), f"W={W} r{r} {name}: {d:.3e}"
+
+
+def test_dropout_argument_checks(single_rank_group):
+    """dropout_p outside [0, 1), dropout together with a window, and a dropout call at world size 1 through every
+    public function family (oracle backend)"""
+    import torch
+    import ring_flash_attn as R
+    from ring_flash_attn import backend
+    from oracle.oracle_backend import OracleBackend
+
+    backend.set_backend(OracleBackend())
+    try:
+        g = torch.Generator().manual_seed(1)
+        q = torch.randn(1, 64, 2, 32, generator=g).bfloat16().requires_grad_(True)
+        with pytest.raises(ValueError):
+            R.ring_flash_attn_func(q, q, q, dropout_p=1.0, causal=True)
+        with pytest.raises(NotImplementedError):
+            R.ring_flash_attn_func(q, q, q, dropout_p=0.1, causal=True, window_size=(8, 0))
+        base = R.zigzag_ring_flash_attn_func(q, q, q, causal=True)
+        for fn in (R.ring_flash_attn_func, R.zigzag_ring_flash_attn_func, R.stripe_flash_attn_func):
+            torch.manual_seed(3)
+            a = fn(q, q, q, dropout_p=0.3, causal=True)
+            torch.manual_seed(3)
+            b = fn(q, q, q, dropout_p=0.3, causal=True)
+            c = fn(q, q, q, dropout_p=0.3, causal=True)          # next draw of the generator: another mask
+            assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, base)
+            a.sum().backward()
+            assert torch.isfinite(q.grad).all()
+        cu = torch.tensor([0, 24, 64], dtype=torch.int32)
+        qv = torch.randn(64, 2, 32, generator=g).bfloat16()
+        for fn in (R.ring_flash_attn_varlen_func, R.zigzag_ring_flash_attn_varlen_func):
+            torch.manual_seed(5)
+            a = fn(qv, qv, qv, cu, 40, dropout_p=0.3, causal=True)
+            assert not torch.equal(a, fn(qv, qv, qv, cu, 40, causal=True))
+    finally:
+        backend.set_backend(None)
+
+
 def test_exchange_mode_auto_threshold(monkeypatch):
     """auto = gather while the O(S_total) scratch fits RFA_GATHER_MAX_BYTES, ring beyond"""
     import torch
