@@ -125,7 +125,13 @@ typedef struct {
   uint64_t dropout_seed;
   int64_t q_pos_offset, k_pos_offset;
   int32_t head_offset;
+  /* Kernel form (tuning / tests; 0 = chosen by the library): RFA_FWD_8x32 = 8 waves x 32 query rows, two waves per SIMD
+   * (csrc/rfa_fwd.hip: every head dim, windows, dropout); RFA_FWD_4x64 = 4 waves x 64 rows, one wave per SIMD with O
+   * and Q in the accumulator registers (csrc/rfa_fwd64.hip: head dim 128 without window / dropout; ignored otherwise) */
+  int32_t fwd_form;
 } rfa_fwd_args;
+
+enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_4x64 = 2 };
 
 typedef struct {
   const void *dout, *out; /* (B,Sq,H,D) io dtype */

@@ -46,6 +46,17 @@ inline bool drop_args_ok(float p, int window, int wl, int wr, int causal) {
 
 }  // namespace
 
+// forward kernel form: the 4 x 64 form covers head dim 128 without window / dropout
+#ifndef RFA_FWD_DEFAULT_4x64
+#define RFA_FWD_DEFAULT_4x64 0
+#endif
+static bool fwd_use_4x64(const rfa_fwd_args* a) {
+  const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
+  if (a->D != kHeadDim || win || a->dropout_p > 0.f) return false;
+  if (a->fwd_form == RFA_FWD_AUTO) return RFA_FWD_DEFAULT_4x64 != 0;
+  return a->fwd_form == RFA_FWD_4x64;
+}
+
 extern "C" {
 
 int rfa_abi_version(void) { return RFA_ABI_VERSION; }
@@ -107,7 +118,9 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   const int rows = fwd_qrows_per_block();
-  p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
+  p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;       // (both forms: 256 rows per workgroup)
+  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x64) return RFA_ERR_ARGS;
+  if (fwd_use_4x64(a)) return launch_status(launch_fwd64(p, a->dtype, (hipStream_t)stream));
   return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
 }
 

@@ -17,6 +17,7 @@ BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
 BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
 BWD_KV_OVERWRITE = 16     # dk_acc / dv_acc are overwritten (dq_acc still follows acc_init)
 DKDV_AUTO, DKDV_128, DKDV_256 = 0, 1, 2
+FWD_AUTO, FWD_8x32, FWD_4x64 = 0, 1, 2
 
 
 class Strides(C.Structure):
@@ -42,6 +43,7 @@ class FwdArgs(C.Structure):
         ("window", C.c_int32), ("window_left", C.c_int32), ("window_right", C.c_int32),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
+        ("fwd_form", C.c_int32),
     ]
 
 

@@ -113,6 +113,7 @@ class HipBackend:
             a.window, a.window_left, a.window_right = 1, int(window[0]), int(window[1])
         a.dtype = self._dtype(q)
         _set_dropout(a, dropout)
+        a.fwd_form = _fwd_form()
         _C.check(self.lib.rfa_fwd(C.byref(a), _stream(q)), "rfa_fwd")
 
     # ------------------------------------------------------------------ backward
@@ -334,6 +335,13 @@ def _set_dropout(a, dropout):
     p, seed, q0, k0, h0 = dropout
     a.dropout_p, a.dropout_seed = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF
     a.q_pos_offset, a.k_pos_offset, a.head_offset = int(q0), int(k0), int(h0)
+
+
+def _fwd_form() -> int:
+    """RFA_FWD_FORM = 8x32 | 4x64 (tuning / tests); unset: the library's choice"""
+    import os
+    v = os.environ.get("RFA_FWD_FORM", "").lower()
+    return {"": _C.FWD_AUTO, "auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x64": _C.FWD_4x64}[v]
 
 
 def _spill_enabled() -> bool:
