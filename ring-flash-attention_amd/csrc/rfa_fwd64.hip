@@ -23,6 +23,26 @@
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
 
+#ifndef RFA_F64_EXP_IN_QK
+#define RFA_F64_EXP_IN_QK 12
+#endif
+// measurement-only switches (results are wrong when one is 0): loop cost without the exponentials / the running max /
+// the LDS fragment reads / the per-tile wait + barrier / the tile DMA
+#ifndef RFA_F64_X_EXP
+#define RFA_F64_X_EXP 1
+#endif
+#ifndef RFA_F64_X_MAX
+#define RFA_F64_X_MAX 1
+#endif
+#ifndef RFA_F64_X_LDS
+#define RFA_F64_X_LDS 1
+#endif
+#ifndef RFA_F64_X_SYNC
+#define RFA_F64_X_SYNC 1
+#endif
+#ifndef RFA_F64_X_DMA
+#define RFA_F64_X_DMA 1
+#endif
 #ifndef RFA_F64_DEFER
 #define RFA_F64_DEFER 8      // deferred rescale threshold in log2 units (as RFA_FWD_DEFER)
 #endif
@@ -35,32 +55,35 @@ constexpr int kF64QRows = kF64Waves * 64;           // 256 query rows per workgr
 constexpr int kF64KV = 64;
 constexpr int kF64TileBytes = kF64KV * 256;         // 16 KiB
 constexpr int kF64Smem = 4 * kF64TileBytes;         // K[2] + V[2]
-// accumulator-file map (asm-owned): O of query block qb, d block dblk: a[64 qb + 16 dblk .. +15];
-// Q fragment of query block qb, k-step kk: a[128 + 32 qb + 4 kk .. +3]
-constexpr int kAO = 0, kAQ = 128, kANum = 192;
+// accumulator-file map (asm-owned, the TOP 192 registers): O of query block qb, d block dblk: a[64 + 64 qb + 16 dblk .. +15];
+// Q fragment of query block qb, k-step kk: a[192 + 32 qb + 4 kk .. +3].  a0 .. a63 stay the compiler's: hipcc uses free
+// accumulator registers as spill space for arch VGPRs and hands them out from a0 upwards.  Every asm statement of
+// this file lists a64 .. a255 as clobbered (nothing of the compiler's may live there across them), and
+// tests/test_abi.py audits the generated code: no compiler-issued v_accvgpr_* names a register above a63.
+constexpr int kAO = 64, kAQ = 192;
 
-#define RFA_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
-#define RFA_ACC_CLOBBERS                                                                                             \
-  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", RFA_A8(1), RFA_A8(2), RFA_A8(3), RFA_A8(4), RFA_A8(5), \
-      RFA_A8(6), RFA_A8(7), RFA_A8(8), RFA_A8(9), RFA_A8(10), RFA_A8(11), RFA_A8(12), RFA_A8(13), RFA_A8(14),        \
-      RFA_A8(15), RFA_A8(16), RFA_A8(17), RFA_A8(18), "a190", "a191"
+#define RFA_A10(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define RFA_ACC_CLOBBERS                                                                                              \
+  "a64", "a65", "a66", "a67", "a68", "a69", RFA_A10(7), RFA_A10(8), RFA_A10(9), RFA_A10(10), RFA_A10(11), RFA_A10(12), \
+      RFA_A10(13), RFA_A10(14), RFA_A10(15), RFA_A10(16), RFA_A10(17), RFA_A10(18), RFA_A10(19), RFA_A10(20),         \
+      RFA_A10(21), RFA_A10(22), RFA_A10(23), RFA_A10(24), "a250", "a251", "a252", "a253", "a254", "a255"
 
 // ---- asm-owned accumulator file -------------------------------------------------------------------------------
 template <int N>
-__device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(N)); }
+__device__ __forceinline__ void acc_zero() { asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(N) : RFA_ACC_CLOBBERS); }
 template <int N>
-__device__ __forceinline__ void acc_write(int v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(v), "i"(N)); }
+__device__ __forceinline__ void acc_write(int v) { asm volatile("v_accvgpr_write_b32 a%c1, %0" ::"v"(v), "i"(N) : RFA_ACC_CLOBBERS); }
 template <int N>
 __device__ __forceinline__ float acc_read() {
   float v;
-  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(N));
+  asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(N) : RFA_ACC_CLOBBERS);
   return v;
 }
 template <int N>
 __device__ __forceinline__ void acc_scale(float alpha) {
   float t;
   asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0"
-               : "=&v"(t) : "v"(alpha), "i"(N));
+               : "=&v"(t) : "v"(alpha), "i"(N) : RFA_ACC_CLOBBERS);
 }
 template <int B0, int... I>
 __device__ __forceinline__ void acc_zero_range(std::integer_sequence<int, I...>) { (acc_zero<B0 + I>(), ...); }
@@ -73,11 +96,11 @@ __device__ __forceinline__ void acc_read16(f32x16& x, std::integer_sequence<int,
 template <typename T, int QA, bool kFirst>
 __device__ __forceinline__ void mfma_s(f32x16& s, vec8<T> k) {
   if constexpr (std::is_same<T, bf16_t>::value) {
-    if constexpr (kFirst) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(k), "i"(QA), "i"(QA + 3));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "i"(QA), "i"(QA + 3));
+    if constexpr (kFirst) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(k), "i"(QA), "i"(QA + 3) : RFA_ACC_CLOBBERS);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "i"(QA), "i"(QA + 3) : RFA_ACC_CLOBBERS);
   } else {
-    if constexpr (kFirst) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(k), "i"(QA), "i"(QA + 3));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "i"(QA), "i"(QA + 3));
+    if constexpr (kFirst) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(s) : "v"(k), "i"(QA), "i"(QA + 3) : RFA_ACC_CLOBBERS);
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(k), "i"(QA), "i"(QA + 3) : RFA_ACC_CLOBBERS);
   }
 }
 // O[qb][dblk] (accumulator file) += V^T fragment x P fragment (both arch VGPRs).  kFresh: P was written by VALU
@@ -85,11 +108,11 @@ __device__ __forceinline__ void mfma_s(f32x16& s, vec8<T> k) {
 template <typename T, int OA, bool kFresh>
 __device__ __forceinline__ void mfma_o(vec8<T> v, vec8<T> pfrag) {
   if constexpr (std::is_same<T, bf16_t>::value) {
-    if constexpr (kFresh) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15));
+    if constexpr (kFresh) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15) : RFA_ACC_CLOBBERS);
+    else asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15) : RFA_ACC_CLOBBERS);
   } else {
-    if constexpr (kFresh) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15));
-    else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15));
+    if constexpr (kFresh) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15) : RFA_ACC_CLOBBERS);
+    else asm volatile("v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(v), "v"(pfrag), "i"(OA), "i"(OA + 15) : RFA_ACC_CLOBBERS);
   }
 }
 
@@ -97,7 +120,7 @@ template <typename T>
 __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
-  // reserve the accumulator registers this kernel owns (the kernel descriptor allocates what is clobbered)
+  // a64 .. a255 are this kernel's (see the map above)
   asm volatile("" ::: RFA_ACC_CLOBBERS);
 
   const int tid = threadIdx.x;
@@ -161,17 +184,34 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
   int kmax = lk;
   if (hi && qend + off < kmax) kmax = qend + off;
   const int ntiles = kmax > 0 ? (kmax + kF64KV - 1) / kF64KV : 0;
+  // tiles this WAVE computes: a causal wave stops at its own diagonal (its rows see nothing beyond) and only keeps
+  // issuing its share of the tile DMA and taking part in the barriers for the tiles the later waves still need
+  int ntiles_w = ntiles;
+  if (hi) {
+    const int last_key = qw0 + 63 + off;
+    const int n = last_key >= 0 ? last_key / kF64KV + 1 : 0;
+    ntiles_w = n < ntiles ? n : ntiles;
+  }
+  if (qw0 >= lq) ntiles_w = 0;
 
   // ---- tile staging by LDS-DMA: 16 pieces of 1 KiB per tile, 4 per wave; lane L of piece c lands in row 4c + L/16,
   // physical chunk L%16 and fetches the logical chunk the swizzle puts there (rfa_common.hpp: dma_lane_src)
-  int voff_k[4], voff_v[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  // (pieces wave, wave + 4, wave + 8, wave + 12 of a tile are 16 rows apart and share their swizzle: ONE per-lane
+  //  byte offset per tensor, the piece advance goes through the scalar offset of the buffer instruction)
+  int voff_k0, voff_v0;
+  {
     int row, chunk;
-    dma_lane_src<128>(wave + kF64Waves * i, lane, row, chunk);
-    voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
-    voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
+    dma_lane_src<128>(wave, lane, row, chunk);
+    voff_k0 = (row * (int)p.k_st.row + chunk * 8) * 2;
+    voff_v0 = (row * (int)p.v_st.row + chunk * 8) * 2;
   }
+  const int kstep = __builtin_amdgcn_readfirstlane(16 * (int)p.k_st.row * 2), vstep = __builtin_amdgcn_readfirstlane(16 * (int)p.v_st.row * 2);
+  auto dma = [&](dma_rsrc_t r, int lds_wave_base, int voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                 :
+                 : "v"(voffset), "s"(r.w), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base)), "s"(soffset)
+                 : "m0", RFA_ACC_CLOBBERS);
+  };
   auto load_k = [&](int j, auto stage) {             // K tile j -> K stage
     constexpr int kStage = decltype(stage)::value;
     int rows = lk - j * kF64KV;
@@ -179,7 +219,7 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
     const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
     const dma_rsrc_t rk = make_dma_rsrc(kbase + (int64_t)j * kF64KV * p.k_st.row, nk);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_load128(rk, lds_addr(smem) + kStage * kF64TileBytes + (wave + kF64Waves * i) * 1024, voff_k[i]);
+    for (int i = 0; i < 4; ++i) dma(rk, lds_addr(smem) + kStage * kF64TileBytes + (wave + kF64Waves * i) * 1024, voff_k0, i * kstep);
   };
   auto load_v = [&](int j, auto stage) {             // V tile j -> V stage
     constexpr int kStage = decltype(stage)::value;
@@ -189,24 +229,18 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
     const dma_rsrc_t rv = make_dma_rsrc(vbase + (int64_t)j * kF64KV * p.v_st.row, nv);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      dma_load128(rv, lds_addr(smem) + (2 + kStage) * kF64TileBytes + (wave + kF64Waves * i) * 1024, voff_v[i]);
+      dma(rv, lds_addr(smem) + (2 + kStage) * kF64TileBytes + (wave + kF64Waves * i) * 1024, voff_v0, i * vstep);
   };
 
-  // ---- per-lane LDS addresses (absolute; the loop only adds immediates)
-  int koff[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    koff[kk] = lds_addr(smem) + tile_off_d<128>(l31, 2 * kk + g);
-    pin_vgpr(koff[kk]);
-  }
-  int voff[4][2];
-#pragma unroll
-  for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      voff[dblk][hh] = lds_addr(smem) + tr_off_d<128>(lane, dblk, 8 * hh + 4 * g);
-      pin_vgpr(voff[dblk][hh]);
-    }
+  // ---- per-lane LDS addresses.  The swizzle makes chunk selection an XOR on address bits 4..7, so a fragment's
+  // address is (one base register) ^ (kk << 5) resp. ^ (dblk << 6) plus an immediate — 3 address registers instead of
+  // 16 (the dynamic LDS block starts at 0: these kernels have no static LDS; checked below)
+  if (lds_addr(smem) & 0xffff) __builtin_trap();
+  int kaddr = lds_addr(smem) + tile_off_d<128>(l31, g);                       // K fragment kk: kaddr ^ (kk << 5)
+  int vaddr[2];                                                               // V^T fragment (dblk, hh): vaddr[hh] ^ (dblk << 6)
+  vaddr[0] = lds_addr(smem) + tr_off_d<128>(lane, 0, 4 * g);
+  vaddr[1] = lds_addr(smem) + tr_off_d<128>(lane, 0, 8 + 4 * g);
+  pin_vgpr(kaddr); pin_vgpr(vaddr[0]); pin_vgpr(vaddr[1]);
 
   const float c = p.scale * kLog2e;
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
@@ -226,50 +260,52 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
   // One wave per SIMD issues in order: an MFMA occupies the matrix pipe for 32 cycles while the VALU / LDS
   // instructions placed behind it issue; `__builtin_amdgcn_sched_barrier(0)` pins that placement (the compiler
   // would otherwise gather the VALU work into one block in front of the MFMAs it feeds).
-  constexpr int kAhead = 3;
-  auto kfrag = [&](int i, int kbo) { return lds_read128<T>(lds_ptr(koff[i % 8]) + kbo + (i / 8) * 32 * 256); };
+  constexpr int kAhead = 2;
+  constexpr int kExpInQK = RFA_F64_EXP_IN_QK;   // exp units (of 16) issued beside the QK MFMAs; the rest beside the first PV MFMAs
+  constexpr int kVAhead = 2;                 // V^T fragments read ahead of their MFMAs
+  auto kfrag = [&](int i, int kbo) {
+    if (!RFA_F64_X_LDS) return __builtin_bit_cast(vec8<T>, i32x4{kaddr, vaddr[0], vaddr[1], i});
+    return lds_read128<T>(lds_ptr(kaddr ^ ((i % 8) << 5)) + kbo + (i / 8) * 32 * 256);
+  };
   auto vfrag = [&](int ks, int dblk, int vbo) {
     const int imm = vbo + 16 * ks * 256;
-    return concat<T>(lds_read_tr<T>(lds_ptr(voff[dblk][0]) + imm), lds_read_tr<T>(lds_ptr(voff[dblk][1]) + imm));
+    if (!RFA_F64_X_LDS) return __builtin_bit_cast(vec8<T>, i32x4{kaddr, vaddr[0], vaddr[1], imm});
+    return concat<T>(lds_read_tr<T>(lds_ptr(vaddr[0] ^ (dblk << 6)) + imm), lds_read_tr<T>(lds_ptr(vaddr[1] ^ (dblk << 6)) + imm));
   };
   float mc[2] = {0.f, 0.f};              // (row max) * c the exponentials of the current tile use
   float psum[2] = {0.f, 0.f};            // row sums of the current tile
   float mx[2];                           // running max of the next tile's scores
 
-  // exp unit u (0..15) of `s`: scores r = 4 (u & 3) .. +3 of sub-tile t = u >> 2 (wait: 16 regs per (t, qb))
-  auto exp_unit = [&](f32x16 (&s)[2][2], auto uc) {
-    constexpr int u = decltype(uc)::value;
-    constexpr int t = u / 8, r0 = 2 * (u % 8);           // 2 scores per query block and (t, r0) -> 16 units x 4 scores
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float pv_ = fast_exp2(__builtin_fmaf(s[t][qb][r0 + e], c, -mc[qb]));
-        s[t][qb][r0 + e] = pv_;
-        psum[qb] += pv_;
-      }
-    // anchor: the results exist HERE, between the volatile MFMA statements around this call (LLVM would otherwise sink
-    // the exponentials down to their first use, the P pack of the PV phase, across any scheduling barrier)
-    asm volatile("" : "+v"(s[t][0]), "+v"(s[t][1]), "+v"(psum[0]), "+v"(psum[1]));
-  };
-  // max unit u (0..15) of `s` of tile j: mask + running max of the same 4 scores
-  auto max_unit = [&](f32x16 (&s)[2][2], int j, auto mask_c, auto uc) {
-    constexpr int u = decltype(uc)::value;
-    constexpr bool need_mask = decltype(mask_c)::value;
+  // exp unit u (0..15) of `s`, query block qb: the 2 scores r0 = 2 (u % 8), r0 + 1 of sub-tile t = u / 8
+  // (16 units x 2 query blocks x 2 scores = the 64 scores a lane holds per tile)
+  auto exp_unit = [&](f32x16 (&s)[2][2], auto uc, auto qbc) {
+    constexpr int u = decltype(uc)::value, qb = decltype(qbc)::value;
     constexpr int t = u / 8, r0 = 2 * (u % 8);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      if (need_mask) {
-        const int qrow = qw0 + 32 * qb + l31;
-        const int lim = hi ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-          if (j * kF64KV + 32 * t + crow(r0 + e, g) > lim) s[t][qb][r0 + e] = -INFINITY;
-      }
-      mx[qb] = fmaxf(mx[qb], fmaxf(s[t][qb][r0], s[t][qb][r0 + 1]));
+    for (int e = 0; e < 2; ++e) {
+      const float pv_ = fast_exp2(__builtin_fmaf(s[t][qb][r0 + e], c, -mc[qb]));
+      s[t][qb][r0 + e] = pv_;
+      psum[qb] += pv_;
     }
-    if (need_mask) asm volatile("" : "+v"(s[t][0]), "+v"(s[t][1]), "+v"(mx[0]), "+v"(mx[1]));
-    else asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));
+    // anchor: the results exist HERE, between the volatile MFMA statements around this call (LLVM would otherwise sink
+    // the exponentials down to their first use, the P pack of the PV phase, across any scheduling barrier)
+    asm volatile("" : "+v"(s[t][qb]), "+v"(psum[qb]) : : RFA_ACC_CLOBBERS);
+  };
+  // max unit u (0..15) of `s` of tile j, query block qb: mask + running max of the same 2 scores
+  auto max_unit = [&](f32x16 (&s)[2][2], int j, auto mask_c, auto uc, auto qbc) {
+    constexpr int u = decltype(uc)::value, qb = decltype(qbc)::value;
+    constexpr bool need_mask = decltype(mask_c)::value;
+    constexpr int t = u / 8, r0 = 2 * (u % 8);
+    if (need_mask) {
+      const int qrow = qw0 + 32 * qb + l31;
+      const int lim = hi ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (j * kF64KV + 32 * t + crow(r0 + e, g) > lim) s[t][qb][r0 + e] = -INFINITY;
+    }
+    mx[qb] = fmaxf(mx[qb], fmaxf(s[t][qb][r0], s[t][qb][r0 + 1]));
+    if (need_mask) asm volatile("" : "+v"(s[t][qb]), "+v"(mx[qb]) : : RFA_ACC_CLOBBERS);
+    else asm volatile("" : "+v"(mx[qb]) : : RFA_ACC_CLOBBERS);
   };
   auto tile_needs_mask = [&](int j) {
     const int kt0 = j * kF64KV;
@@ -291,10 +327,10 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
         const float alpha = fast_exp2(m[qb] * c - msafe * c);
         m[qb] = mnew;
         lsum[qb] *= alpha;
-        asm volatile("s_nop 11");                       // MFMA D (accumulator file) -> accvgpr read
+        asm volatile("s_nop 11" ::: RFA_ACC_CLOBBERS);  // MFMA D (accumulator file) -> accvgpr read
         if (qb == 0) acc_scale_range<kAO>(alpha, std::make_integer_sequence<int, 64>{});
         else acc_scale_range<kAO + 64>(alpha, std::make_integer_sequence<int, 64>{});
-        asm volatile("s_nop 3");                        // accvgpr write -> MFMA C read
+        asm volatile("s_nop 3" ::: RFA_ACC_CLOBBERS);   // accvgpr write -> MFMA C read
       }
       mc[qb] = ((m[qb] == -INFINITY) ? 0.f : m[qb]) * c;
     }
@@ -314,9 +350,12 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
     {                                                                                                              \
       if (i + kAhead < 16) a[i + kAhead] = kfrag(i + kAhead, kbo);                                                \
       mfma_s<T, kAQ + 4 * (i % 8), (i % 8) == 0>(nxt[i / 8][0], a[i]);                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      if (RFA_F64_X_EXP && kExp && i < kExpInQK) exp_unit(cur, std::integral_constant<int, i>{}, st0{});          \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
       mfma_s<T, kAQ + 32 + 4 * (i % 8), (i % 8) == 0>(nxt[i / 8][1], a[i]);                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      if (kExp) exp_unit(cur, std::integral_constant<int, i>{});                                                   \
+      if (RFA_F64_X_EXP && kExp && i < kExpInQK) exp_unit(cur, std::integral_constant<int, i>{}, st1{});          \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
     RFA_F64_SEQ16(RFA_F64_QK)
@@ -329,7 +368,7 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
     vec8<T> vf[16];
     vec8<T> pb0, pb1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) vf[i] = vfrag(0, i, vbo);
+    for (int i = 0; i < kVAhead; ++i) vf[i] = vfrag(0, i, vbo);
 #define RFA_F64_PV(i)                                                                                             \
     {                                                                                                              \
       constexpr int ks = i / 4, dblk = i % 4;                                                                      \
@@ -337,11 +376,16 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
         pb0 = pack8<T>(cur[ks / 2][0], 8 * (ks % 2));                                                              \
         pb1 = pack8<T>(cur[ks / 2][1], 8 * (ks % 2));                                                              \
       }                                                                                                            \
-      if (i + 4 < 16) vf[i + 4] = vfrag((i + 4) / 4, (i + 4) % 4, vbo);                                            \
+      if (i + kVAhead < 16) vf[i + kVAhead] = vfrag((i + kVAhead) / 4, (i + kVAhead) % 4, vbo);                    \
       mfma_o<T, kAO + 16 * dblk, dblk == 0>(vf[i], pb0);                                                           \
-      mfma_o<T, kAO + 64 + 16 * dblk, false>(vf[i], pb1);                                                          \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
-      if (kMax) max_unit(nxt, jn, need_mask, std::integral_constant<int, i>{});                                    \
+      if (RFA_F64_X_EXP && kMax && kExpInQK + i < 16) exp_unit(cur, std::integral_constant<int, (kExpInQK + i) % 16>{}, st0{}); \
+      if (RFA_F64_X_MAX && kMax) max_unit(nxt, jn, need_mask, std::integral_constant<int, i>{}, st0{});            \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      mfma_o<T, kAO + 64 + 16 * dblk, dblk == 0>(vf[i], pb1);   /* (the compiler may convert pb1 right here) */     \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      if (RFA_F64_X_EXP && kMax && kExpInQK + i < 16) exp_unit(cur, std::integral_constant<int, (kExpInQK + i) % 16>{}, st1{}); \
+      if (RFA_F64_X_MAX && kMax) max_unit(nxt, jn, need_mask, std::integral_constant<int, i>{}, st1{});            \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
     RFA_F64_SEQ16(RFA_F64_PV)
@@ -357,48 +401,67 @@ __global__ __launch_bounds__(kF64Threads, 1) void fwd64_kernel(const FwdParams p
   wait_all_vmem();
   __syncthreads();
   f32x16 sa[2][2], sb[2][2];
-  if (ntiles > 0) {
+  if (ntiles_w > 0) {
     qk_phase(sa, sb, st0{}, no_t{});
-    asm volatile("s_nop 11" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]));   // MFMA D -> VALU reader
+    asm volatile("s_nop 11" : "+v"(sa[0][0]), "+v"(sa[0][1]), "+v"(sa[1][0]), "+v"(sa[1][1]) : : RFA_ACC_CLOBBERS);   // MFMA D -> VALU reader
     mx[0] = mx[1] = -INFINITY;
-#define RFA_F64_MX(i) max_unit(sa, 0, yes_t{}, std::integral_constant<int, i>{});
+#define RFA_F64_MX(i) max_unit(sa, 0, yes_t{}, std::integral_constant<int, i>{}, st0{}); max_unit(sa, 0, yes_t{}, std::integral_constant<int, i>{}, st1{});
     RFA_F64_SEQ16(RFA_F64_MX)
 #undef RFA_F64_MX
     finalize();
   }
   __syncthreads();                                     // every wave is done with K(0) before K(2) overwrites it
 
-  auto iter = [&](int j, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], auto par) {
+  // tile DMA of iteration j (K two tiles ahead, V one) and the end-of-iteration hand-over
+  auto dma_for = [&](int j, auto par) {
     constexpr int kPar = decltype(par)::value;                 // j & 1
+    if (RFA_F64_X_DMA && j + 2 < ntiles) load_k(j + 2, std::integral_constant<int, kPar>{});       // K stage j&1 held K(j): read in the previous iteration
+    if (RFA_F64_X_DMA && j + 1 < ntiles) load_v(j + 1, std::integral_constant<int, kPar ^ 1>{});   // V stage (j+1)&1 held V(j-1)
+  };
+  auto sync = [&]() {
+    if (RFA_F64_X_SYNC) {
+      wait_all_vmem();
+      __syncthreads();
+    }
+    // (every path through an iteration crosses a statement that owns a64 .. a255)
+    asm volatile("" ::: RFA_ACC_CLOBBERS);
+  };
+  // One iteration = one tile of the WORKGROUP: the tile DMA, this wave's work on it, the barrier.  Wave-uniform modes:
+  //   j + 1 < ntiles_w   the tile has a successor: everything overlapped (cur = S(j) -> P(j), nxt = S(j+1))
+  //   j + 1 == ntiles_w  this wave's last tile: nothing to overlap with
+  //   j >= ntiles_w      only the later waves still compute (or j is the padding slot of an odd tile count)
+  // The loop always runs whole PAIRS of iterations with no branch between them: the S buffers swap roles inside the
+  // pair and are back in place at the loop edge (a conditional second half costs 128 register moves per trip).
+  auto iter = [&](int j, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], auto par) {
+    constexpr int kPar = decltype(par)::value;
     typedef std::integral_constant<int, kPar> same_t;
     typedef std::integral_constant<int, kPar ^ 1> other_t;
-    if (j + 2 < ntiles) load_k(j + 2, same_t{});               // K stage j&1 held K(j): read in the previous iteration
-    if (j + 1 < ntiles) load_v(j + 1, other_t{});              // V stage (j+1)&1 held V(j-1): read in the previous iteration
-    if (j + 1 < ntiles) {
+    dma_for(j, par);
+    if (j + 1 < ntiles_w) {
       qk_phase(nxt, cur, other_t{}, yes_t{});
       mx[0] = mx[1] = -INFINITY;
       if (tile_needs_mask(j + 1)) pv_phase(cur, nxt, j + 1, yes_t{}, same_t{}, yes_t{});     // (diagonal / tail tiles)
       else pv_phase(cur, nxt, j + 1, no_t{}, same_t{}, yes_t{});
       finalize();
-    } else {                                                   // last tile: nothing to overlap with
-#define RFA_F64_EX(i) exp_unit(cur, std::integral_constant<int, i>{});
+    } else if (j + 1 == ntiles_w) {
+#define RFA_F64_EX(i) exp_unit(cur, std::integral_constant<int, i>{}, st0{}); exp_unit(cur, std::integral_constant<int, i>{}, st1{});
       RFA_F64_SEQ16(RFA_F64_EX)
 #undef RFA_F64_EX
       pv_phase(cur, nxt, 0, no_t{}, same_t{}, no_t{});
       lsum[0] += psum[0];
       lsum[1] += psum[1];
+      asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]) : : RFA_ACC_CLOBBERS);
     }
-    wait_all_vmem();
-    __syncthreads();
+    sync();
   };
   for (int j = 0; j < ntiles; j += 2) {
     iter(j, sa, sb, st0{});
-    if (j + 1 < ntiles) iter(j + 1, sb, sa, st1{});
+    iter(j + 1, sb, sa, st1{});
   }
 #undef RFA_F64_SEQ16
 
   // ---------------- epilogue (per query block; as rfa_fwd.hip) ----------------
-  asm volatile("s_nop 11");                              // last MFMAs -> accvgpr reads
+  asm volatile("s_nop 11" ::: RFA_ACC_CLOBBERS);         // last MFMAs -> accvgpr reads
   auto finish = [&](auto qbc) {
     constexpr int qb = decltype(qbc)::value;
     const int qrow = qw0 + 32 * qb + l31;

@@ -655,3 +655,54 @@ def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
         _check(f"r{r}.out", got["out"], ro[sl], 0, kind="out_ring")
         for name, ref in (("dq", dq), ("dk", dk), ("dv", dv)):
             _check(f"r{r}.{name}", got[name], ref[sl], 0, kind="grad_ring")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the 4 x 64 forward form (csrc/rfa_fwd64.hip, opt-in: RFA_FWD_FORM=4x64 / rfa_fwd_args.fwd_form)
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,causal,dtype", [
+    (1, 1000, 1000, 4, 2, True, BF),            # odd tile count of the last workgroup, masked tails
+    (2, 300, 777, 2, 2, True, BF),              # bottom-right aligned, odd number of key tiles
+    (1, 513, 513, 2, 1, False, BF),             # one valid row in the last workgroup
+    (1, 256, 64, 1, 1, False, BF),              # a single key tile
+    (1, 900, 260, 2, 2, True, torch.float16),   # queries without any visible key (lse = +inf), fp16 MFMAs
+])
+def test_fwd_4x64_form_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, causal, dtype):
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    monkeypatch.setenv("RFA_FWD_FORM", "4x64")
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q = torch.randn(B, Sq, H, 128, generator=g).to(dtype)
+    k = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
+    v = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
+    if Sq == 1000:                                   # spike keys: the deferred-rescale branch in the middle of the loop
+        k[0, 300] = q[0, 400, 0:2] * 3.0
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, 128 ** -0.5, causal)
+    out = torch.empty(B, Sq, H, 128, dtype=dtype, device=dev)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+    be.fwd(q.to(dev), k.to(dev), v.to(dev), softmax_scale=128 ** -0.5, causal=causal, out=out, lse=lse)
+    _check("4x64.out", out, ro, 0, kind="out")
+    _check("4x64.lse", lse, rl, 0, kind="lse")
+
+
+def test_fwd_4x64_form_in_the_schedules(single_rank_group, monkeypatch):
+    """packed sequences, half-sequence selectors and the fused fp32 merge epilogue: the zigzag varlen schedule forced
+    onto its multi-step path (RFA_TEST_FORCE_STEPS) with the 4 x 64 forward form, against the 8 x 32 form"""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    monkeypatch.setenv("RFA_TEST_FORCE_STEPS", "1")
+    g = torch.Generator().manual_seed(64)
+    cu = torch.tensor([0, 128, 1248, 2240], dtype=torch.int32, device=dev)
+    q = torch.randn(2240, 4, 128, generator=g).to(BF).to(dev)
+    k = torch.randn(2240, 2, 128, generator=g).to(BF).to(dev)
+    v = torch.randn(2240, 2, 128, generator=g).to(BF).to(dev)
+    res = {}
+    for form in ("8x32", "4x64"):
+        monkeypatch.setenv("RFA_FWD_FORM", form)
+        out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(q, k, v, cu, 1120, causal=True, return_attn_probs=True)
+        res[form] = (out.float().cpu(), lse.cpu())
+    _check("4x64 vs 8x32 out", res["4x64"][0], res["8x32"][0], 0, kind="out")
+    _check("4x64 vs 8x32 lse", res["4x64"][1], res["8x32"][1], 0, kind="lse")
