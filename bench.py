@@ -113,12 +113,12 @@ def kernel_breakdown(q, kv, dout, cu=None):
 
 
 def library_digest():
-    """sha256 (first 16 hex digits) of the librfa_hip.so this process loads: profiles/*_traffic.json carries the
-    digest of the BINARY its counters were collected on (written on the GPU box by profiles/collect_pmc.sh at
-    collection time), and is only quoted when it is this binary"""
+    """rfa_build_id() of the librfa_hip.so this process loads (the digest of its sources, compiled into the binary):
+    profiles/*_traffic.json carries the id of the library its counters were collected on — read from that library on
+    the GPU box at collection time by profiles/collect_pmc.sh — and is only quoted for the same build"""
     from ring_flash_attn import _C
 
-    return hashlib.sha256(open(_C.LIB_PATH, "rb").read()).hexdigest()[:16]
+    return _C.load().rfa_build_id().decode()
 
 
 def committed_traffic(kernel, hk):
@@ -132,7 +132,7 @@ def committed_traffic(kernel, hk):
     if best is None or hk != 8:
         return None, "no PMC traffic pass committed for this configuration"
     tr = json.load(open(os.path.join(pdir, best)))
-    have = tr.get("library_sha16")
+    have = tr.get("library_build_id")
     if have != library_digest():
         sys.stderr.write(f"bench.py: profiles/{best} was collected on another build of librfa_hip.so "
                          f"({have} vs {library_digest()}): roofline.traffic withheld — re-run profiles/collect_pmc.sh\n")

@@ -245,6 +245,10 @@ typedef struct {
 } rfa_merge_args;
 
 int rfa_abi_version(void);
+/* identity of this build: the first 16 hex digits of the sha256 over the library's sources, compiled into the binary by
+ * the build recipe (ring-flash-attention_amd/build.py).  Measurement files (profiles/*_traffic.json) record the id of
+ * the library they were collected on; bench.py only quotes them for a library with the same id. */
+const char *rfa_build_id(void);
 const char *rfa_strerror(int status);
 
 int rfa_fwd(const rfa_fwd_args *args, void *stream);

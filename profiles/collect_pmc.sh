@@ -5,8 +5,8 @@
 #               MI355X_MICROARCH.md prescribes; FETCH_SIZE and WRITE_SIZE cannot share a pass)
 # over the PRODUCT path (python bench.py: 5-GEMM backward with the dS spill), a few steps each.
 # Output: gpurun_out/prof/<pass>/...; summaries: gpurun_out/prof/<tag>_*.txt (+ <tag>_traffic.json, which
-# carries the sha256 of the librfa_hip.so the counters were collected on, taken HERE at collection time —
-# bench.py refuses to quote the file for any other binary).
+# carries rfa_build_id() of the librfa_hip.so the counters were collected on, read from that library HERE at
+# collection time — bench.py refuses to quote the file for any other build).
 #   usage: bash profiles/collect_pmc.sh r03        (then copy gpurun_out/prof/r03_* into profiles/)
 set -u
 TAG=${1:-r03}
@@ -26,6 +26,6 @@ cd $R
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH"; python profiles/summarize_rocpd.py $(find $OUT/kt -name "*_results.db" | head -1); grep '^{' $OUT/kt.log | tail -1; } > $OUT/${TAG}_bench_kernel_trace_stats.txt 2>&1
 { echo "# separate rocprofv3 --pmc passes over: $SHORT   (per-dispatch averages per counter instance)";
   for p in sq lds fetch write; do echo "== pass: $p"; python profiles/summarize_rocpd.py $(find $OUT/$p -name "*_results.db" | head -1) --pmc | sed -n '/per-dispatch counter averages/,$p' | tail -n +2; done; } > $OUT/${TAG}_pmc_counters.txt 2>&1
-LIBSHA=$(sha256sum $R/ring-flash-attention_amd/ring_flash_attn/librfa_hip.so | cut -c1-16)
+LIBSHA=$(cd $R && python -c "import sys; sys.path.insert(0, 'ring-flash-attention_amd'); from ring_flash_attn import _C; print(_C.load().rfa_build_id().decode())")
 python profiles/make_traffic.py $OUT/${TAG}_pmc_counters.txt $OUT/${TAG}_traffic.json $LIBSHA
 tail -5 $OUT/${TAG}_bench_kernel_trace_stats.txt; cat $OUT/${TAG}_traffic.json

@@ -5,8 +5,8 @@ x 1024 (every store of these kernels is 16 bytes wide), next to
   algorithmic_bytes  what the operation has to move (inputs once, outputs once) — the dS hand-off is NOT in it
   handoff_bytes      the dS blocks this implementation writes (dK/dV kernel) / reads back (dQ kernel): traffic the
                      5-GEMM design creates, reported separately so that the counter bytes can be read against both
-and the sha256 of the librfa_hip.so the counters were collected on (argument 3: taken by collect_pmc.sh on the GPU
-box at collection time; bench.py only quotes `roofline.traffic` for that binary)."""
+and rfa_build_id() of the librfa_hip.so the counters were collected on (argument 3: read from that library by
+collect_pmc.sh on the GPU box at collection time; bench.py only quotes `roofline.traffic` for the same build)."""
 import json
 import os
 import re
@@ -44,7 +44,7 @@ def main():
                 break
     out = {"_source": f"{os.path.basename(src)} (profiles/collect_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                       "over python bench.py, headline shape Hk=8, per launch); FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024",
-           "library_sha16": sys.argv[3] if len(sys.argv) > 3 else None}
+           "library_build_id": sys.argv[3] if len(sys.argv) > 3 else None}
     for key, v in vals.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             out[key] = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],

@@ -69,8 +69,10 @@ def build_lib(force=False):
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if not force and not _stale(LIB, deps):
         return LIB
+    # the build id (rfa_build_id()): digest of exactly the sources that go into the binary
+    build_id = _digest(deps)[:16]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-inline-asm"]
+           "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-inline-asm", f'-DRFA_BUILD_ID="{build_id}"']
     cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES]
     cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
     cmd += ["-o", LIB]

@@ -61,6 +61,11 @@ extern "C" {
 
 int rfa_abi_version(void) { return RFA_ABI_VERSION; }
 
+#ifndef RFA_BUILD_ID
+#define RFA_BUILD_ID "unstamped"
+#endif
+const char* rfa_build_id(void) { return RFA_BUILD_ID; }
+
 const char* rfa_strerror(int status) {
   switch (status) {
     case RFA_OK: return "ok";

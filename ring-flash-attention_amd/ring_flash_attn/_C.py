@@ -116,6 +116,7 @@ class SumSlotsArgs(C.Structure):
 # every symbol include/rfa.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rfa_abi_version": (C.c_int, []),
+    "rfa_build_id": (C.c_char_p, []),
     "rfa_strerror": (C.c_char_p, [C.c_int]),
     "rfa_fwd": (C.c_int, [C.POINTER(FwdArgs), C.c_void_p]),
     "rfa_bwd_preprocess": (C.c_int, [C.POINTER(BwdPreArgs), C.c_void_p]),
