@@ -64,3 +64,22 @@ def test_sliding_window_is_honoured(single_rank_group):
     finally:
         backend.set_backend(None)
         A.DATA_PARAMS.clear()
+
+
+def test_sliding_window_through_the_adapter_over_several_ranks():
+    """the adapter's sliding-window path had no multi-rank test.  A Qwen3 whose layers all use sliding
+    attention (window 8) runs through substitute_hf_flash_attn on 1, 2 and 4 gloo ranks (llama3 schedule: the window
+    is applied by ONE kernel call over the gathered keys, with flash_attn's (w, w) semantics as the reference adapter
+    forwards it): logits and parameter gradients must not depend on the number of ranks, and must differ from the
+    same model without a window."""
+    cfg = dict(CFG, sliding_window=8, use_sliding_window=True, max_window_layers=0,
+               layer_types=["sliding_attention"] * CFG["num_hidden_layers"])
+    cu = [0, 23, 70, 96]
+    one, g_one = AW.run_world(1, cfg, cu, use_hip=False, heads_k_stride=1, port=free_port())
+    full, _ = AW.run_world(1, CFG, cu, use_hip=False, heads_k_stride=1, port=free_port())
+    assert (one - full).abs().max() > 1e-3, "the window changed nothing"
+    for W in (2, 4):
+        logits, grads = AW.run_world(W, cfg, cu, use_hip=False, heads_k_stride=1, port=free_port())
+        assert (logits - one).abs().max() < 2e-4 * max(1.0, one.abs().max().item()), W
+        for n, g in g_one.items():
+            assert (grads[n] - g).abs().max() <= 5e-4 * max(1.0, g.abs().max().item()), (W, n)
