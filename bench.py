@@ -172,22 +172,44 @@ class _Hip:
 
 
 class InStepTimer:
-    """Backend wrapper that times every launch INSIDE the real step: the public function runs unchanged — same
-    launches, same stream, same order, same data — with HIP events recorded between the launches (before / after
-    every backend call; inside rfa_bwd by the library itself through rfa_bwd_args.prof_events: after its first
-    kernel, its second kernel and the reduction pass).  Installed through ring_flash_attn.backend.set_backend for a
-    few extra steps after the timed region; the timed region itself runs the plain backend."""
+    """Backend wrapper that times the launches INSIDE the real step: the public function runs unchanged — same
+    launches, same stream, same order, same data.  To keep the measurement from perturbing what it measures (a HIP
+    event between two kernels is a barrier packet of its own: with every launch of a step bracketed the intervals came
+    out up to 8 % longer than rocprofv3's kernel trace of the same run), each instrumented step brackets ONE launch
+    kind only, in rotation (fwd / bwd_preprocess / dK/dV / dQ / reduce / the side kernels): before and after the
+    backend call, or — inside rfa_bwd — through rfa_bwd_args.prof_events, of which only the two needed entries are
+    given.  Events are created before the steps.  Installed through ring_flash_attn.backend.set_backend for a few
+    extra steps after the timed region; the timed region itself runs the plain backend."""
 
-    def __init__(self, be):
+    KINDS = ("fwd", "bwd_preprocess", "bwd_first", "bwd_second", "bwd_reduce", "side", "empty")
+
+    def __init__(self, be, nevents=4096):
         self.be, self.hip, self.calls = be, _Hip(), []
+        self.pool = [self.hip.event() for _ in range(nevents)]
+        self.kind = None          # what the current step brackets
+        self.counts = {}          # launches per kind over ALL instrumented steps
+
+    def _ev(self):
+        return self.pool.pop()
 
     def __getattr__(self, name):
         fn = getattr(self.be, name)
         if name not in ("fwd", "bwd_preprocess", "cast", "sum_slots", "merge"):
             return fn
+        kind = name if name in ("fwd", "bwd_preprocess") else "side"
 
         def timed(*a, **kw):
-            e0, e1 = self.hip.event(), self.hip.event()
+            self.counts[name] = self.counts.get(name, 0) + 1
+            if self.kind == "empty" and name == "fwd" and len(self.pool) >= 2:
+                # calibration: a bracket with nothing inside, at a kernel boundary of the real step — what the two event
+                # packets themselves add to every bracketed interval
+                e0, e1 = self._ev(), self._ev()
+                self.hip.record(e0)
+                self.hip.record(e1)
+                self.calls.append(("empty", e0, e1))
+            if self.kind != kind or not self.pool:
+                return fn(*a, **kw)
+            e0, e1 = self._ev(), self._ev()
             self.hip.record(e0)
             r = fn(*a, **kw)
             self.hip.record(e1)
@@ -197,30 +219,33 @@ class InStepTimer:
         return timed
 
     def bwd(self, *a, **kw):
-        ev = (self.hip.C.c_void_p * 4)(*[self.hip.event() for _ in range(4)])
+        self.counts["bwd"] = self.counts.get("bwd", 0) + 1
+        slot = {"bwd_first": 0, "bwd_second": 1, "bwd_reduce": 2}.get(self.kind)
+        if slot is None or len(self.pool) < 2:
+            return self.be.bwd(*a, **kw)
+        e0, e1 = self._ev(), self._ev()
+        ev = (self.hip.C.c_void_p * 4)()
+        ev[slot], ev[slot + 1] = e0, e1
         r = self.be.bwd(*a, prof_events=ev, **kw)
-        self.calls.append(("bwd", ev, None))
+        self.calls.append((self.kind, e0, e1))
         return r
 
     def totals(self, spill):
-        """{launch name: (ms summed over the recorded steps, launches)}"""
-        first, second = ("bwd_dkdv", "bwd_dq") if spill else ("bwd_dq", "bwd_dkdv")
+        """{launch name: (ms summed over the bracketed launches, bracketed launches)}"""
+        names = {"bwd_first": "bwd_dkdv" if spill else "bwd_dq", "bwd_second": "bwd_dq" if spill else "bwd_dkdv"}
         tot = {}
-
-        def add(n, ms):
-            t = tot.setdefault(n, [0.0, 0])
+        empty = [self.hip.ms(e0, e1) for name, e0, e1 in self.calls if name == "empty"]
+        self.overhead_ms = sum(empty) / len(empty) if empty else 0.0
+        for name, e0, e1 in self.calls:
+            if name == "empty":
+                continue
+            ms = self.hip.ms(e0, e1)
+            if name == "bwd_reduce" and ms < 2e-3 + self.overhead_ms:
+                continue                          # a call without a reduction pass
+            ms = max(ms - self.overhead_ms, 0.0)  # the bracket's own event packets (calibrated above)
+            t = tot.setdefault(names.get(name, name), [0.0, 0])
             t[0] += ms
             t[1] += 1
-
-        for name, e0, e1 in self.calls:
-            if name == "bwd":
-                add(first, self.hip.ms(e0[0], e0[1]))
-                add(second, self.hip.ms(e0[1], e0[2]))
-                red = self.hip.ms(e0[2], e0[3])
-                if red > 1e-3:
-                    add("bwd_reduce", red)
-            else:
-                add(name, self.hip.ms(e0, e1))
         return tot
 
 
@@ -312,8 +337,8 @@ def comm_bytes_per_iter(mode, wire_fp32, world, hk):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a 0.4 s timed region at N = 1)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kv-heads", type=int, default=8, help="8 = the reference benchmark's GQA; 32 = MHA")
     ap.add_argument("--workload", default="zigzag", choices=["zigzag", "zigzag_varlen", "llama3"],
                     help="zigzag = the BASELINE.json headline; the others mirror benchmark_varlen_kvpacked_func.py")
@@ -553,21 +578,32 @@ def main():
 
         timer = InStepTimer(rfa_backend.get_backend())
         rfa_backend.set_backend(timer)
-        nprof = max(1, min(args.steps, 10))
+        rounds = max(2, min(args.steps // 4, 6))            # instrumented steps = rounds x kinds, one kind per step
         try:
-            step()                                   # (events and the wrapper warm)
-            torch.cuda.synchronize()
-            timer.calls = []
+            step()                                   # (the wrapper warm; nothing bracketed)
+            timer.counts = {}
             counter[0] = 0
-            for _ in range(nprof):
-                step()
+            nprof = 0
+            for _ in range(rounds):
+                for kind in InStepTimer.KINDS:
+                    timer.kind = kind
+                    step()
+                    nprof += 1
             torch.cuda.synchronize()
         finally:
+            timer.kind = None
             rfa_backend.set_backend(None)
         spill = os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
         tot = timer.totals(spill)
-        instep = {n: {"ms_per_step": t[0] / nprof, "launches_per_step": t[1] / nprof, "avg_launch_ms": t[0] / t[1]}
-                  for n, t in tot.items()}
+        bwd_calls = timer.counts.get("bwd", 0) / nprof
+        per_step = {"fwd": timer.counts.get("fwd", 0) / nprof, "bwd_preprocess": timer.counts.get("bwd_preprocess", 0) / nprof,
+                    "bwd_dkdv": bwd_calls, "bwd_dq": bwd_calls, "bwd_reduce": bwd_calls}
+        instep = {}
+        for n, t in tot.items():
+            launches = per_step.get(n, timer.counts.get(n, 0) / nprof)
+            if n == "bwd_reduce":                     # only the calls that made a reduction pass were counted
+                launches = bwd_calls * t[1] / max(1, sum(1 for c in timer.calls if c[0] == "bwd_reduce"))
+            instep[n] = {"avg_launch_ms": t[0] / t[1], "launches_per_step": launches, "ms_per_step": t[0] / t[1] * launches}
 
     if rank == 0 and instep is not None:
         with torch.no_grad():
@@ -585,10 +621,13 @@ def main():
             "sum_ms": round(sum_ms, 4),
             "ms_per_step": round(ms, 4),
             "other_ms": round(ms - sum_ms, 4),
+            "bracket_overhead_ms": round(timer.overhead_ms, 5),
             "consistent": bool(sum_ms <= ms * 1.02),
-            "how": f"HIP events between the launches of the real step (InStepTimer: backend calls of the public "
-                   f"function, rfa_bwd_args.prof_events inside the backward), {nprof} instrumented steps after the "
-                   f"timed region; other_ms = ms_per_step - sum (host gaps, autograd, grad buffers)",
+            "how": f"HIP events around ONE launch kind per instrumented step, in rotation (InStepTimer: backend calls of "
+                   f"the public function, rfa_bwd_args.prof_events inside the backward), {nprof} instrumented steps "
+                   f"after the timed region; ms = (average bracketed interval - bracket_overhead_ms, the interval of an "
+                   f"EMPTY bracket at a kernel boundary of the same steps) x launches per step; other_ms = ms_per_step "
+                   f"- sum (host gaps, autograd, grad buffers)",
         }
         if world == 1 and wl == "zigzag":
             # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the

@@ -14,8 +14,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
-BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
-SHORT="python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown"
+BENCH="python $R/bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline"
+SHORT="python $R/bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-breakdown"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- $BENCH > $OUT/kt.log 2>&1
 run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o $name -- $SHORT > $OUT/$name.log 2>&1; }
 run sq    SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16

@@ -660,6 +660,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (RFA_KV_X_LOAD && f + 1 < ntile) load_tile();
     int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
     bool active = false;
+    // dS scratch rows of this tile's two sub-tiles (wave-uniform; once per tile, outside the MFMA blocks)
+    const int64_t ds_roff0 = kSpill ? ds_row_off(2 * j, ds_nkb, p.ds_c, 1) : 0;
+    const int ds_rlen0 = kSpill ? ds_row_len(2 * j, ds_nkb, p.ds_c, 1) : 0;
     // parity form: the one sub-tile t = par; kWide: both, one after the other (the sub-tile lives in address
     // bit 13 of the Q/dO fragment bases and bit 7 of the statistics base: toggled, not re-computed)
 #if RFA_KV_WIDE_UNROLL
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         auto spill = [&]() {
           if (!kSpill || RFA_SPILL_PROBE == 1) return;
           const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes +
-                            (ds_row_off(2 * j + t, ds_nkb, p.ds_c, 1) + ds_kb) * kDsBlockBytes;
+                            (ds_roff0 + (t ? ds_rlen0 : 0) + ds_kb) * kDsBlockBytes;
           if (RFA_SPILL_PROBE == 4) blk = ds_b + (int64_t)(blockIdx.x * 8 + wave) * kDsBlockBytes;
           const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds0), rb, ds_lane, 0, RFA_SPILL_AUX);

@@ -241,10 +241,10 @@ class HipBackend:
         if sbytes <= 0:
             return None
         limit = _spill_limit()
-        if sbytes <= limit and device.type == "cuda":
+        if _SPILL_CHECK_ABOVE < sbytes <= limit and device.type == "cuda":
+            # (small requests skip the query: it costs host time on every backward)
             free, _ = torch.cuda.mem_get_info(device)
-            st = torch.cuda.memory_stats(device)
-            cached = st.get("reserved_bytes.all.current", 0) - st.get("allocated_bytes.all.current", 0)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
             limit = min(limit, int(_spill_frac() * (free + cached)))
         if sbytes > limit:
             _log_once("spill-limit", f"ring_flash_attn: dS spill of {sbytes / 2**30:.2f} GiB refused (limit "
@@ -372,6 +372,8 @@ def _plan_overrides():
         form = _C.DKDV_256
     return form, max(nsplit, 0)
 
+
+_SPILL_CHECK_ABOVE = 256 << 20      # bytes: scratch requests up to this size are simply attempted
 
 _LOGGED = set()
 

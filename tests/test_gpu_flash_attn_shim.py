@@ -128,8 +128,24 @@ def test_public_functions_autograd(built):
     cu = torch.tensor([0, S], dtype=torch.int32, device=dev)
     o3, l3, _ = FA.flash_attn_varlen_qkvpacked_func(qkv[0].to(dev), cu, S, causal=True, return_attn_probs=True)
     assert torch.equal(o3, out.detach()[0]) and l3.shape == (H, S)
-    with pytest.raises(NotImplementedError):
-        FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p=0.1)
+    # dropout through the public function (the seed is drawn from torch's CPU generator and kept on the autograd node):
+    # against the oracle with the same seed — forward and backward
+    from ring_flash_attn._common import draw_dropout_seed
+
+    xd = qkv.to(dev).requires_grad_(True)
+    torch.manual_seed(321)
+    od = FA.flash_attn_func(xd[:, :, 0], xd[:, :, 1], xd[:, :, 2], dropout_p=0.1, causal=True)
+    od.backward(do.to(dev))
+    torch.manual_seed(321)
+    rng = torch.tensor([draw_dropout_seed(), 0])
+    rod, rld, _, _ = O._flash_attn_forward(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.1, D ** -0.5, True, rng_state=rng)
+    gq, gk, gv = (torch.empty_like(qkv[:, :, 0]) for _ in range(3))
+    O._flash_attn_backward(do, qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], rod, rld, gq, gk, gv, 0.1, D ** -0.5, True, rng_state=rng)
+    _check("dropout out", od, rod, 2e-2)
+    _check("dropout dqkv", xd.grad, torch.stack([gq, gk, gv], dim=2), 1e-2, 2e-2)
+    assert (od.detach() - out.detach()).abs().max() > 0.05
+    with pytest.raises(NotImplementedError):                       # dropout together with a window
+        FA.flash_attn_func(q, kv[:, :, 0], kv[:, :, 1], dropout_p=0.1, window_size=(64, 0), causal=True)
     # sliding window through the public function: against the oracle with the same window
     xw = qkv.to(dev).requires_grad_(True)
     ow = FA.flash_attn_qkvpacked_func(xw, window_size=(128, 0), causal=True)
