@@ -60,7 +60,7 @@ typedef enum {
   RFA_OK = 0,
   RFA_ERR_NULL = -1,        /* required pointer is NULL                       */
   RFA_ERR_DTYPE = -2,       /* dtype not RFA_BF16 / RFA_F16                    */
-  RFA_ERR_HEAD_DIM = -3,    /* head_dim not a multiple of 8 or > 128           */
+  RFA_ERR_HEAD_DIM = -3,    /* head_dim not a multiple of 8 or > 256           */
   RFA_ERR_HEADS = -4,       /* H not a multiple of Hk                          */
   RFA_ERR_SHAPE = -5,       /* negative / zero extents                         */
   RFA_ERR_ALIGN = -6,       /* pointer or stride breaks the 16-byte contract   */

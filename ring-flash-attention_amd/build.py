@@ -24,7 +24,7 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "libattn_ref.so")
 SELFTEST_SRC = os.path.join(ROOT, "tests", "native", "selftest.cpp")
 SELFTEST_BIN = os.path.join(ROOT, "tests", "native", "selftest")
 
-HIP_SOURCES = ["rfa_fwd.hip", "rfa_fwd64.hip", "rfa_bwd.hip", "rfa_dqs.hip", "rfa_aux.hip"]
+HIP_SOURCES = ["rfa_fwd.hip", "rfa_fwd64.hip", "rfa_bwd.hip", "rfa_bigd.hip", "rfa_dqs.hip", "rfa_aux.hip"]
 API_SOURCE = "rfa_api.cpp"
 HEADERS = ["rfa_common.hpp", "rfa_kernels.hpp", os.path.join(ROOT, "include", "rfa.h")]
 

@@ -20,7 +20,7 @@ inline bool stride_ok(const rfa_strides& s, int elt_bytes) {
 
 inline int check_common(int dtype, int H, int Hk, int D, int B) {
   if (dtype != RFA_BF16 && dtype != RFA_F16) return RFA_ERR_DTYPE;
-  if (D <= 0 || D > kHeadDim || (D % 8) != 0) return RFA_ERR_HEAD_DIM;
+  if (D <= 0 || D > kMaxHeadDim || (D % 8) != 0) return RFA_ERR_HEAD_DIM;
   if (H <= 0 || Hk <= 0 || (H % Hk) != 0) return RFA_ERR_HEADS;
   if (B < 0) return RFA_ERR_SHAPE;
   return RFA_OK;
@@ -71,7 +71,7 @@ const char* rfa_strerror(int status) {
     case RFA_OK: return "ok";
     case RFA_ERR_NULL: return "a required pointer is NULL";
     case RFA_ERR_DTYPE: return "unsupported dtype (only bf16 / fp16)";
-    case RFA_ERR_HEAD_DIM: return "head_dim must be a multiple of 8 and <= 128";
+    case RFA_ERR_HEAD_DIM: return "head_dim must be a multiple of 8 and <= 256";
     case RFA_ERR_HEADS: return "nheads must be a positive multiple of nheads_k";
     case RFA_ERR_SHAPE: return "negative or inconsistent extent";
     case RFA_ERR_ALIGN: return "pointer/stride violates the 16-byte alignment contract";
@@ -125,6 +125,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   const int rows = fwd_qrows_per_block();
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;       // (both forms: 256 rows per workgroup)
   if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x64) return RFA_ERR_ARGS;
+  if (a->D > kHeadDim) return launch_status(launch_fwd_big(p, a->dtype, (hipStream_t)stream));
   if (fwd_use_4x64(a)) return launch_status(launch_fwd64(p, a->dtype, (hipStream_t)stream));
   return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
 }

@@ -30,11 +30,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const PreParams p) {
   const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
   const int64_t arow = qs.row0 + row;
   float acc = 0.f;
-  if (sub * 8 < p.D) {
+  for (int d = sub * 8; d < p.D; d += 128) {                 // (one pass for head dims <= 128)
     const vec8<T> a = *(const vec8<T>*)((const T*)p.dout + qbatch * p.dout_st.batch +
-                                        arow * p.dout_st.row + (int64_t)h * p.dout_st.head + sub * 8);
+                                        arow * p.dout_st.row + (int64_t)h * p.dout_st.head + d);
     const vec8<T> o = *(const vec8<T>*)((const T*)p.out + qbatch * p.out_st.batch +
-                                        arow * p.out_st.row + (int64_t)h * p.out_st.head + sub * 8);
+                                        arow * p.out_st.row + (int64_t)h * p.out_st.head + d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)o[e];
   }
@@ -58,14 +58,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
   const int64_t rh = item >> 4;
   const int row = (int)(rh / p.Hk);
   const int hk = (int)(rh % p.Hk);
-  if (row >= ks.len || sub * 8 >= p.D) return;
+  if (row >= ks.len) return;
   const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
   const int64_t arow = ks.row0 + row;
+  for (int d = sub * 8; d < p.D; d += 128) {                 // (one pass for head dims <= 128)
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   const TS* sp = (const TS*)(second ? p.src2 : p.src) + kbatch * p.src_st.batch + arow * p.src_st.row +
-                 (int64_t)(p.g_stride ? hk : hk * p.G) * p.src_st.head + sub * 8;
+                 (int64_t)(p.g_stride ? hk : hk * p.G) * p.src_st.head + d;
   const int64_t gstep = p.g_stride ? p.g_stride : p.src_st.head;
   for (int gq = 0; gq < p.G; ++gq) {
     // io-dtype partials: flash_attn also rounds each block's dK/dV to the io dtype before they are added up in
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
   float* dacc = second ? p.dst_acc2 : p.dst_acc;
   if (dacc) {
     const Strides st = second ? p.dst_acc2_st : p.dst_acc_st;
-    float* dp = dacc + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + sub * 8;
+    float* dp = dacc + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + d;
     f32x4 x0, x1;
     if (p.acc_init) {
 #pragma unroll
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = acc[e];
     const Strides st = second ? p.dst2_st : p.dst_st;
-    T* dp = (T*)(second ? p.dst2 : p.dst) + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + sub * 8;
+    T* dp = (T*)(second ? p.dst2 : p.dst) + kbatch * st.batch + arow * st.row + (int64_t)hk * st.head + d;
     *(vec8<T>*)dp = __builtin_convertvector(x, vec8<T>);
+  }
   }
 }
 
@@ -135,12 +137,12 @@ __global__ __launch_bounds__(256) void merge_kernel(const MergeParams p) {
       wo = eo / den; wb = eb / den; lnew = mx + __logf(den);
     }
   }
-  if (sub * 8 < p.D) {
+  for (int d = sub * 8; d < p.D; d += 128) {                 // (one pass for head dims <= 128)
     float* op = p.out_acc + (int64_t)b * p.out_acc_st.batch + (int64_t)row * p.out_acc_st.row +
-                (int64_t)h * p.out_acc_st.head + sub * 8;
+                (int64_t)h * p.out_acc_st.head + d;
     const vec8<T> bv = *(const vec8<T>*)((const T*)p.block_out + (int64_t)b * p.block_out_st.batch +
                                          (int64_t)row * p.block_out_st.row +
-                                         (int64_t)h * p.block_out_st.head + sub * 8);
+                                         (int64_t)h * p.block_out_st.head + d);
     f32x4 x0, x1;
     if (p.acc_init) {
 #pragma unroll

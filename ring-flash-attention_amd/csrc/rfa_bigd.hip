@@ -1,0 +1,782 @@
+// rfa_bigd.hip — attention forward and backward for head dims 129 … 256 on gfx950 (MI355X).
+//
+// flash_attn accepts head dims up to 256 and the reference only asks for d % 8 == 0
+// (/root/reference/test/test_zigzag_ring_flash_attn_func.py:35); the tuned kernels of rfa_fwd.hip / rfa_bwd.hip are
+// built around one 128-column LDS tile and 256 registers per wave and stop at 128.  The three kernels here cover
+// the rest with the same parameter blocks, masks, merge / accumulate epilogues and dropout mask, so that every
+// schedule runs unchanged (rfa_api.cpp sends D > 128 here):
+//   * a head is handled as TWO 128-column chunks: an LDS tile [rows][256] is two of the swizzled [rows][128] chunk
+//     tiles of rfa_common.hpp back to back, so the fragment reads (row-per-lane ds_read_b128, ds_read_b64_tr_b16)
+//     and the LDS-DMA lane mapping are the ones of the 128-wide kernels plus a chunk offset; D < 256 is zero padded
+//     by pointing the DMA lanes of the missing 16-byte chunks past the buffer range (they then write zeros);
+//   * 4 waves per workgroup = one wave per SIMD with the whole 512-entry register file: the Q (and dO) fragments of a
+//     256-wide row are 64 (128) registers, the O / dQ accumulators 128, dK + dV 256;
+//   * forward / dQ: a wave owns 32 query rows, 64-key K/V tiles, two LDS stages (128 KiB);
+//     dK/dV: a wave owns 32 keys with K_w, V_w as register B operands, 32-row Q/dO tiles of all query heads of the
+//     K/V group, two LDS stages (64 KiB), dK/dV of the group summed in registers (7-GEMM backward, no dS spill).
+// These are coverage kernels, written for clarity: no hand-placed schedules.  Measured rates are in DESIGN.md §3.2.
+#include "rfa_common.hpp"
+#include "rfa_kernels.hpp"
+
+namespace rfa {
+
+constexpr int kBgWaves = 4;
+constexpr int kBgThreads = kBgWaves * 64;
+constexpr int kBgRows = kBgWaves * 32;        // query rows (forward, dQ) / keys (dK/dV) per workgroup
+constexpr int kBgNK = 16;                     // 16-wide k-steps of a contraction over 256 columns
+constexpr int kBgNB = 8;                      // 32-wide column blocks of an accumulator row
+constexpr int kBgOob = 0x7ffffff0;            // byte offset past every descriptor range: the lane reads / DMAs zeros
+
+// Per-lane global byte offsets of the LDS-DMA pieces one wave issues for a wide tile of R rows.  Piece P (1 KiB =
+// 4 rows of a chunk tile) belongs to chunk c = P / (R / 4); waves take the pieces wave, wave + 4, ...
+template <int R>
+__device__ __forceinline__ void big_dma_offsets(int wave, int lane, int row_stride, int D, int (&voff)[R / 8]) {
+#pragma unroll
+  for (int i = 0; i < R / 8; ++i) {
+    const int P = wave + kBgWaves * i;
+    const int c = P / (R / 4), pc = P % (R / 4);
+    int row, ch;
+    dma_lane_src<128>(pc, lane, row, ch);
+    const int col = 128 * c + 8 * ch;
+    voff[i] = col < D ? (row * row_stride + col) * 2 : kBgOob;
+  }
+}
+template <int R>
+__device__ __forceinline__ void big_dma_tile(dma_rsrc_t r, int lds_base, int wave, const int (&voff)[R / 8]) {
+#pragma unroll
+  for (int i = 0; i < R / 8; ++i) {
+    const int P = wave + kBgWaves * i;
+    const int c = P / (R / 4), pc = P % (R / 4);
+    dma_load128(r, lds_base + c * R * 256 + pc * 1024, voff[i]);
+  }
+}
+
+// =====================================================================================
+// forward
+// =====================================================================================
+constexpr int kBgKV = 64;                          // keys per K/V tile (forward, dQ)
+constexpr int kBgChunkTile = kBgKV * 256;          // [64][128] chunk tile
+constexpr int kBgTile = 2 * kBgChunkTile;          // [64][256]
+constexpr int kBgFwdSmem = 4 * kBgTile;            // K[2] V[2]: 128 KiB
+
+template <typename T>
+__global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int gq = idx % G;
+  idx /= G;
+  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
+  const int b = idx / p.nqblk;
+  const int h = hk * G + gq;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int qwg0 = qblk * kBgRows;
+  if (qwg0 >= lq) return;
+  const int off = lk - lq;
+  const int qw0 = qwg0 + wave * 32;
+  const int qrow = qw0 + l31;
+  const int qrow_c = qrow < lq ? qrow : lq - 1;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+
+  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + (qs.row0 + qrow_c) * p.q_st.row + (int64_t)h * p.q_st.head;
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
+
+  vec8<T> qf[kBgNK];
+#pragma unroll
+  for (int kk = 0; kk < kBgNK; ++kk) {
+    const int d0 = 16 * kk + 8 * g;
+    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+  }
+
+  const int qend = (qwg0 + kBgRows < lq) ? qwg0 + kBgRows : lq;
+  const bool win = p.wl >= 0 || (p.wr >= 0 && !p.causal);       // (rfa_kernels.hpp: windowed)
+  const bool hi = win ? p.wr >= 0 : p.causal != 0;
+  const bool lo = win && p.wl >= 0;
+  const int wr = win ? p.wr : 0, wl = win ? p.wl : 0;
+  int kmax = lk;
+  if (hi && qend + off + wr < kmax) kmax = qend + off + wr;
+  const int ntiles = kmax > 0 ? (kmax + kBgKV - 1) / kBgKV : 0;
+  int kmin = lo ? qwg0 + off - wl : 0;
+  kmin = kmin > 0 ? kmin : 0;
+  const int jt0 = kmin / kBgKV;
+
+  int voff_k[kBgKV / 8], voff_v[kBgKV / 8];
+  big_dma_offsets<kBgKV>(wave, lane, (int)p.k_st.row, p.D, voff_k);
+  big_dma_offsets<kBgKV>(wave, lane, (int)p.v_st.row, p.D, voff_v);
+  auto load_tile = [&](int j, int stage) {
+    int rows = lk - j * kBgKV;
+    rows = rows < kBgKV ? rows : kBgKV;
+    const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
+    const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
+    const dma_rsrc_t rk = make_dma_rsrc(kbase + (int64_t)j * kBgKV * p.k_st.row, nk);
+    const dma_rsrc_t rv = make_dma_rsrc(vbase + (int64_t)j * kBgKV * p.v_st.row, nv);
+    big_dma_tile<kBgKV>(rk, lds_addr(smem) + stage * kBgTile, wave, voff_k);
+    big_dma_tile<kBgKV>(rv, lds_addr(smem) + (2 + stage) * kBgTile, wave, voff_v);
+  };
+
+  // fragment addresses inside a chunk tile: K rows (A operand of S^T = K Q^T), V^T by transpose reads
+  int koff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);
+  int voff[4][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) voff[dblk][hh] = lds_addr(smem) + tr_off_d<128>(lane, dblk, 8 * hh + 4 * g);
+
+  const bool drop = p.drop_keep < 256;
+  const uint32_t drop_key = drop ? drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)h) : 0u;
+  const uint32_t drop_i = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) + (uint32_t)qrow : 0u;
+  const uint32_t drop_j0 = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
+  const float c = p.scale * kLog2e;
+  float m = -INFINITY;
+  float lsum = 0.f;
+  f32x16 o[kBgNB];
+#pragma unroll
+  for (int i = 0; i < kBgNB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+  load_tile(jt0, 0);                     // unconditional (rows past the end read as zero)
+  wait_all_vmem();
+  __syncthreads();
+
+  for (int j = jt0; j < ntiles; ++j) {
+    const int stage = (j - jt0) & 1;
+    if (j + 1 < ntiles) load_tile(j + 1, stage ^ 1);
+    const int kbo = stage * kBgTile, vbo = (2 + stage) * kBgTile;
+    const int kt0 = j * kBgKV;
+    const bool active = (qw0 < lq) && !(hi && kt0 > qw0 + 31 + off + wr) && !(lo && kt0 + kBgKV - 1 < qw0 + off - wl);
+    if (active) {
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < kBgNK; ++kk) {
+          const vec8<T> a = lds_read128<T>(lds_ptr(koff[kk & 7]) + kbo + (kk >> 3) * kBgChunkTile + t * 32 * 256);
+          s[t] = mfma(a, qf[kk], s[t]);
+        }
+      }
+      const bool need_mask = (kt0 + kBgKV > lk) || (hi && kt0 + kBgKV - 1 > qw0 + off + wr) || (lo && kt0 < qw0 + 31 + off - wl);
+      if (need_mask) {
+        const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
+        const int lim_lo = lo ? qrow + off - wl : -0x40000000;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt0 + 32 * t + crow(r, g);
+            if (key > lim || key < lim_lo) s[t][r] = -INFINITY;
+          }
+      }
+      float mloc = s[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+      mloc = fmaxf(mloc, shfl_xor32(mloc));
+      const float mnew = fmaxf(m, mloc);
+      if (!__all(mnew == m)) {
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = fast_exp2(m * c - msafe * c);
+        m = mnew;
+        lsum *= alpha;
+#pragma unroll
+        for (int i = 0; i < kBgNB; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+      }
+      const float mc = ((m == -INFINITY) ? 0.f : m) * c;
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = fast_exp2(__builtin_fmaf(s[t][r], c, -mc));
+          s[t][r] = pv;
+          psum += pv;
+        }
+      lsum += psum;
+      if (drop) {
+        // the forward kernel's mask (rfa_fwd.hip): row sum and lse stay those of the undropped softmax
+        const int mis = __builtin_amdgcn_readfirstlane((int)(drop_j0 & 3u));
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) {
+            const uint32_t jg = drop_j0 + (uint32_t)(kt0 + 32 * t + 8 * mm + 4 * g);
+            uint32_t w = drop_word(drop_key, drop_i, jg >> 2);
+            if (mis) w = __builtin_amdgcn_alignbyte(drop_word(drop_key, drop_i, (jg >> 2) + 1), w, (uint32_t)mis);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!drop_keep(w, e, p.drop_keep)) s[t][4 * mm + e] = 0.f;
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const vec8<T> pb = pack8<T>(s[t], 8 * ks2);
+          const int imm = vbo + (32 * t + 16 * ks2) * 256;
+#pragma unroll
+          for (int dblk = 0; dblk < kBgNB; ++dblk) {
+            const int cimm = imm + (dblk >> 2) * kBgChunkTile;
+            vec4<T> lo4 = lds_read_tr<T>(lds_ptr(voff[dblk & 3][0]) + cimm);
+            vec4<T> hi4 = lds_read_tr<T>(lds_ptr(voff[dblk & 3][1]) + cimm);
+            o[dblk] = mfma(concat<T>(lo4, hi4), pb, o[dblk]);
+          }
+        }
+    }
+    wait_all_vmem();           // tile j+1 has landed
+    __syncthreads();
+  }
+
+  if (qrow >= lq) return;
+  const float l = lsum + shfl_xor32(lsum);
+  const bool has = l > 0.f;
+  const float inv = has ? (drop ? p.drop_scale : 1.f) / l : 0.f;
+  const float blse = has ? m * p.scale + __logf(l) : INFINITY;
+  const int64_t orow = qs.row0 + qrow;
+  if (p.out_acc == nullptr) {
+    T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
+    store_rows16<T, false, kBgNB>(ob, o, inv, g, p.D, true);
+    if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
+  } else {
+    // fused online merge into the caller's fp32 accumulators: the epilogue of rfa_fwd.hip
+    float* ab = p.out_acc + qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row + (int64_t)h * p.out_acc_st.head;
+    float* lp = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
+    if (p.acc_init) {
+#pragma unroll
+      for (int dblk = 0; dblk < kBgNB; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = o[dblk][4 * jj + e] * inv;
+            *(f32x4*)(ab + d0) = x;
+          }
+        }
+      if (g == 0) *lp = has ? blse : -INFINITY;
+    } else if (has) {
+      const float lold = *lp;
+      const float mx = fmaxf(lold, blse);
+      const float eo = __expf(lold - mx);
+      const float eb = __expf(blse - mx);
+      const float den = eo + eb;
+      const float wo = eo / den;
+      const float wb = eb / den * inv;
+      const float lnew = mx + __logf(den);
+#pragma unroll
+      for (int dblk = 0; dblk < kBgNB; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x = *(f32x4*)(ab + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] * wo + o[dblk][4 * jj + e] * wb;
+            *(f32x4*)(ab + d0) = x;
+          }
+        }
+      if (g == 0) *lp = lnew;
+    }
+  }
+}
+
+// =====================================================================================
+// dQ (7-GEMM form: S and dP recomputed)
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int gq = idx % G;
+  idx /= G;
+  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
+  const int b = idx / p.nqblk;
+  const int h = hk * G + gq;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int qwg0 = qblk * kBgRows;
+  if (qwg0 >= lq) return;
+  const int off = lk - lq;
+  const int qw0 = qwg0 + wave * 32;
+  const int qrow = qw0 + l31;
+  const int qrow_c = qrow < lq ? qrow : lq - 1;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+  const int64_t arow = qs.row0 + qrow_c;
+
+  const T* qbase = (const T*)p.q + qbatch * p.q_st.batch + arow * p.q_st.row + (int64_t)h * p.q_st.head;
+  const T* dobase = (const T*)p.dout + qbatch * p.dout_st.batch + arow * p.dout_st.row + (int64_t)h * p.dout_st.head;
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
+
+  vec8<T> qf[kBgNK], dof[kBgNK];
+#pragma unroll
+  for (int kk = 0; kk < kBgNK; ++kk) {
+    const int d0 = 16 * kk + 8 * g;
+    qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
+    dof[kk] = d0 < p.D ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
+  }
+  const float L2 = p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + arow] * kLog2e;
+  const float dlt = p.delta[qbatch * p.delta_batch + (int64_t)h * p.delta_head + arow];
+
+  const int qend = (qwg0 + kBgRows < lq) ? qwg0 + kBgRows : lq;
+  const bool win = p.wl >= 0 || (p.wr >= 0 && !p.causal);       // (rfa_kernels.hpp: windowed)
+  const bool hi = win ? p.wr >= 0 : p.causal != 0;
+  const bool lo = win && p.wl >= 0;
+  const int wr = win ? p.wr : 0, wl = win ? p.wl : 0;
+  int kmax = lk;
+  if (hi && qend + off + wr < kmax) kmax = qend + off + wr;
+  const int ntiles = kmax > 0 ? (kmax + kBgKV - 1) / kBgKV : 0;
+  int kmin = lo ? qwg0 + off - wl : 0;
+  kmin = kmin > 0 ? kmin : 0;
+  const int jt0 = kmin / kBgKV;
+
+  int voff_k[kBgKV / 8], voff_v[kBgKV / 8];
+  big_dma_offsets<kBgKV>(wave, lane, (int)p.k_st.row, p.D, voff_k);
+  big_dma_offsets<kBgKV>(wave, lane, (int)p.v_st.row, p.D, voff_v);
+  auto load_tile = [&](int j, int stage) {
+    int rows = lk - j * kBgKV;
+    rows = rows < kBgKV ? rows : kBgKV;
+    const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
+    const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
+    const dma_rsrc_t rk = make_dma_rsrc(kbase + (int64_t)j * kBgKV * p.k_st.row, nk);
+    const dma_rsrc_t rv = make_dma_rsrc(vbase + (int64_t)j * kBgKV * p.v_st.row, nv);
+    big_dma_tile<kBgKV>(rk, lds_addr(smem) + stage * kBgTile, wave, voff_k);
+    big_dma_tile<kBgKV>(rv, lds_addr(smem) + (2 + stage) * kBgTile, wave, voff_v);
+  };
+  int koff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) koff[kk] = lds_addr(smem) + tile_off(l31, 2 * kk + g);
+  int toff[4][2];
+#pragma unroll
+  for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) toff[dblk][hh] = lds_addr(smem) + tr_off_d<128>(lane, dblk, 8 * hh + 4 * g);
+
+  const bool drop = p.drop_keep < 256;
+  const uint32_t drop_key = drop ? drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)h) : 0u;
+  const uint32_t drop_i = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) + (uint32_t)qrow : 0u;
+  const uint32_t drop_j0 = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
+  const float c = p.scale * kLog2e;
+  f32x16 dq[kBgNB];
+#pragma unroll
+  for (int i = 0; i < kBgNB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  load_tile(jt0, 0);
+  wait_all_vmem();
+  __syncthreads();
+
+  for (int j = jt0; j < ntiles; ++j) {
+    const int stage = (j - jt0) & 1;
+    if (j + 1 < ntiles) load_tile(j + 1, stage ^ 1);
+    const int kbo = stage * kBgTile, vbo = (2 + stage) * kBgTile;
+    const int kt0 = j * kBgKV;
+    const bool active = (qw0 < lq) && !(hi && kt0 > qw0 + 31 + off + wr) && !(lo && kt0 + kBgKV - 1 < qw0 + off - wl);
+    if (active) {
+      const bool need_mask = (kt0 + kBgKV > lk) || (hi && kt0 + kBgKV - 1 > qw0 + off + wr) || (lo && kt0 < qw0 + 31 + off - wl);
+      const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
+      const int lim_lo = lo ? qrow + off - wl : -0x40000000;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < kBgNK; ++kk) {
+          const int fo = (kk >> 3) * kBgChunkTile + t * 32 * 256;
+          s = mfma(lds_read128<T>(lds_ptr(koff[kk & 7]) + kbo + fo), qf[kk], s);
+          dp = mfma(lds_read128<T>(lds_ptr(koff[kk & 7]) + vbo + fo), dof[kk], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(__builtin_fmaf(s[r], c, -L2));
+        if (need_mask) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt0 + 32 * t + crow(r, g);
+            s[r] = (key > lim || key < lim_lo) ? 0.f : s[r];
+          }
+        }
+        if (drop) {
+          const int mis = __builtin_amdgcn_readfirstlane((int)(drop_j0 & 3u));
+#pragma unroll
+          for (int mm = 0; mm < 4; ++mm) {
+            const uint32_t jg = drop_j0 + (uint32_t)(kt0 + 32 * t + 8 * mm + 4 * g);
+            uint32_t w = drop_word(drop_key, drop_i, jg >> 2);
+            if (mis) w = __builtin_amdgcn_alignbyte(drop_word(drop_key, drop_i, (jg >> 2) + 1), w, (uint32_t)mis);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp[4 * mm + e] = drop_keep(w, e, p.drop_keep) ? dp[4 * mm + e] * p.drop_scale : 0.f;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
+#pragma unroll
+        for (int ks2 = 0; ks2 < 2; ++ks2) {
+          const vec8<T> dsb = pack8<T>(s, 8 * ks2);
+          const int imm = kbo + (32 * t + 16 * ks2) * 256;
+#pragma unroll
+          for (int dblk = 0; dblk < kBgNB; ++dblk) {
+            const int cimm = imm + (dblk >> 2) * kBgChunkTile;
+            vec4<T> lo4 = lds_read_tr<T>(lds_ptr(toff[dblk & 3][0]) + cimm);
+            vec4<T> hi4 = lds_read_tr<T>(lds_ptr(toff[dblk & 3][1]) + cimm);
+            dq[dblk] = mfma(concat<T>(lo4, hi4), dsb, dq[dblk]);
+          }
+        }
+      }
+    }
+    wait_all_vmem();
+    __syncthreads();
+  }
+
+  if (qrow >= lq) return;
+  const int64_t orow = qs.row0 + qrow;
+  if (p.dq_acc == nullptr) {
+    T* ob = (T*)p.dq + qbatch * p.dq_st.batch + orow * p.dq_st.row + (int64_t)h * p.dq_st.head;
+    store_rows16<T, false, kBgNB>(ob, dq, p.scale, g, p.D, true);
+  } else {
+    float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + orow * p.dq_acc_st.row + (int64_t)h * p.dq_acc_st.head;
+#pragma unroll
+    for (int dblk = 0; dblk < kBgNB; ++dblk)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (d0 < p.D) {
+          f32x4 x;
+          if (p.acc_init) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = 0.f;
+          } else {
+            x = *(f32x4*)(ab + d0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] += dq[dblk][4 * jj + e] * p.scale;
+          *(f32x4*)(ab + d0) = x;
+        }
+      }
+  }
+}
+
+// =====================================================================================
+// dK / dV
+// =====================================================================================
+constexpr int kBgQ = 32;                             // query rows per Q/dO tile
+constexpr int kBgQChunk = kBgQ * 256;                // [32][128] chunk tile: 8 KiB
+constexpr int kBgQTile = 2 * kBgQChunk;              // [32][256]: 16 KiB
+constexpr int kBgOffDo = 2 * kBgQTile;               // dO stages behind the two Q stages
+constexpr int kBgOffStat = 4 * kBgQTile;             // 64 KiB: per stage lse[32] (x -log2 e), delta[32] (x -1)
+constexpr int kBgStatBytes = 2 * kBgQ * 4;
+constexpr int kBgKvSmem = kBgOffStat + 2 * kBgStatBytes;
+
+template <typename T>
+__global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  if (lds_addr(smem) & 0xffff) __builtin_trap();     // the stage / fragment XORs below need a 64 KiB-aligned block
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int kblk = idx % p.nkblk;
+  const int b = idx / p.nkblk;
+  const int h0 = hk * G;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int kwg0 = kblk * kBgRows;
+  if (kwg0 >= lk) return;
+  const int off = lk - lq;
+  const int kw0 = kwg0 + wave * 32;
+  const int krow = kw0 + l31;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
+  const T* qbase0 = (const T*)p.q + qbatch * p.q_st.batch + qs.row0 * p.q_st.row + (int64_t)h0 * p.q_st.head;
+  const T* dobase0 = (const T*)p.dout + qbatch * p.dout_st.batch + qs.row0 * p.dout_st.row + (int64_t)h0 * p.dout_st.head;
+  const float* lsebase0 = p.lse + qbatch * p.lse_batch + (int64_t)h0 * p.lse_head + qs.row0;
+  const float* dltbase0 = p.delta + qbatch * p.delta_batch + (int64_t)h0 * p.delta_head + qs.row0;
+
+  const bool win = p.wl >= 0 || (p.wr >= 0 && !p.causal);       // (rfa_kernels.hpp: windowed)
+  const bool hi = win ? p.wr >= 0 : p.causal != 0;
+  const bool lo = win && p.wl >= 0;
+  const int wr = win ? p.wr : 0, wl = win ? p.wl : 0;
+  int qfirst = 0;
+  if (hi) {
+    qfirst = kwg0 - off - wr;
+    if (qfirst < 0) qfirst = 0;
+  }
+  int qlast = lq;
+  if (lo && kwg0 + kBgRows - off + wl < qlast) qlast = kwg0 + kBgRows - off + wl;
+  const int jt0 = qfirst / kBgQ;
+  int jt1 = (qlast + kBgQ - 1) / kBgQ;
+  if (jt1 <= jt0) jt1 = jt0;
+  const int jtop = jt1 - 1;
+  const int ntile_q = jtop >= jt0 ? jtop - jt0 + 1 : 0;
+
+  // this wave's K and V rows: register B operands of S = Q K_w^T and dP = dO V_w^T
+  vec8<T> kwr[kBgNK], vwr[kBgNK];
+  {
+    const int kr = krow < lk ? krow : lk - 1;
+    const T* kp = kbase + (int64_t)kr * p.k_st.row;
+    const T* vp = vbase + (int64_t)kr * p.v_st.row;
+#pragma unroll
+    for (int kk = 0; kk < kBgNK; ++kk) {
+      const int d0 = 16 * kk + 8 * g;
+      kwr[kk] = d0 < p.D ? *(const vec8<T>*)(kp + d0) : zero8<T>();
+      vwr[kk] = d0 < p.D ? *(const vec8<T>*)(vp + d0) : zero8<T>();
+    }
+  }
+
+  int voff_q[kBgQ / 8], voff_do[kBgQ / 8];
+  big_dma_offsets<kBgQ>(wave, lane, (int)p.q_st.row, p.D, voff_q);
+  big_dma_offsets<kBgQ>(wave, lane, (int)p.dout_st.row, p.D, voff_do);
+  int dma_stage = 0;
+  int ld_g = 0, ld_j = jtop > 0 ? jtop : 0;       // (head in group, tile) of the next load: tiles from the top down, heads inside
+  float statreg = 0.f;
+  auto load_tile = [&]() {
+    const int j = ld_j;
+    const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
+    const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
+    const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
+    const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
+    if (++ld_g >= G) {
+      ld_g = 0;
+      ld_j -= 1;
+    }
+    int rows = lq - j * kBgQ;
+    rows = rows < kBgQ ? rows : kBgQ;
+    const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
+    const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
+    const dma_rsrc_t rq = make_dma_rsrc(qbase + (int64_t)j * kBgQ * p.q_st.row, nq);
+    const dma_rsrc_t rdo = make_dma_rsrc(dobase + (int64_t)j * kBgQ * p.dout_st.row, ndo);
+    big_dma_tile<kBgQ>(rq, lds_addr(smem) + dma_stage, wave, voff_q);
+    big_dma_tile<kBgQ>(rdo, lds_addr(smem) + dma_stage + kBgOffDo, wave, voff_do);
+    if (wave == 0) {                              // lanes 0-31: lse of the tile's rows, lanes 32-63: delta
+      const int r = j * kBgQ + l31;
+      statreg = r < lq && r >= 0 ? (g ? dltbase[r] : lsebase[r]) : 0.f;
+    }
+    dma_stage ^= kBgQTile;
+  };
+  int ws = lds_addr(smem) + kBgOffStat + lane * 4;
+  const float stat_scale = g ? -1.f : -kLog2e;
+  auto write_stats = [&]() {
+    if (wave == 0) *(__attribute__((address_space(3))) float*)lds_ptr(ws) = statreg * stat_scale;
+  };
+
+  int aq = lds_addr(smem) + tile_off(l31, g);                        // Q / dO rows (A operands of S, dP); stage toggled
+  int tq[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) tq[hh] = lds_addr(smem) + tr_off_d<128>(lane, 0, 8 * hh + 4 * g);
+  int sa = lds_addr(smem) + kBgOffStat + 4 * g * 4;                  // row statistics; stage toggled
+
+  const bool drop = p.drop_keep < 256;
+  const uint32_t drop_j = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) + (uint32_t)krow : 0u;
+  const uint32_t drop_i0 = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) : 0u;
+  const float c = p.scale * kLog2e;
+  f32x16 dk[kBgNB], dv[kBgNB];
+#pragma unroll
+  for (int i = 0; i < kBgNB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+
+  load_tile();
+  wait_all_vmem();
+  write_stats();
+  ws ^= kBgStatBytes;
+  __syncthreads();
+
+  const int ntile = ntile_q * G;
+  int j = jtop, cg = 0;
+  for (int f = 0; f < ntile; ++f) {
+    if (f + 1 < ntile) load_tile();
+    const int qs0 = j * kBgQ;
+    const bool active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) && !(lo && qs0 + off - wl > kw0 + 31);
+    if (active) {
+      f32x16 s, dp;
+      f32x4 nd[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]
+        nd[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kBgQ + 8 * jj) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = nd[jj][e]; s[4 * jj + e] = 0.f; }
+      }
+#pragma unroll
+      for (int kk = 0; kk < kBgNK; ++kk) {
+        const int fo = (kk >> 3) * kBgQChunk;
+        const int a = aq ^ ((kk & 7) << 5);
+        s = mfma(lds_read128<T>(lds_ptr(a) + fo), kwr[kk], s);
+        dp = mfma(lds_read128<T>(lds_ptr(a) + fo + kBgOffDo), vwr[kk], dp);
+      }
+      f32x4 l2v[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, l2v[jj][e]));
+      const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) || (lo && qs0 + 31 + off - wl > kw0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = qs0 + crow(r, g);
+          const bool ok = (q < lq) && (!hi || krow <= q + off + wr) && (!lo || krow >= q + off - wl);
+          s[r] = ok ? s[r] : 0.f;
+        }
+      }
+      if (drop) {
+        // the dK/dV kernel's dropout (rfa_bwd.hip): dP = keep ? dO V^T / (1 - p) : 0, dS = P (dP - delta), dV takes keep ? P / (1 - p) : 0
+        const uint32_t hkey = drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)(h0 + cg));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * jj + e;
+            const uint32_t w = drop_word(hkey, drop_i0 + (uint32_t)(qs0 + crow(r, g)), drop_j >> 2);
+            const bool keep = drop_keep(w, (int)(drop_j & 3u), p.drop_keep);
+            const float dpd = keep ? (dp[r] - nd[jj][e]) * p.drop_scale + nd[jj][e] : nd[jj][e];
+            dp[r] = dpd * s[r];
+            s[r] = keep ? s[r] * p.drop_scale : 0.f;
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] *= s[r];
+      }
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const vec8<T> pb = pack8<T>(s, 8 * ks2), dsb = pack8<T>(dp, 8 * ks2);
+#pragma unroll
+        for (int dblk = 0; dblk < kBgNB; ++dblk) {
+          const int imm = 16 * ks2 * 256 + (dblk >> 2) * kBgQChunk;
+          const int a0 = tq[0] ^ ((dblk & 3) << 6), a1 = tq[1] ^ ((dblk & 3) << 6);
+          vec4<T> lo4 = lds_read_tr<T>(lds_ptr(a0) + imm + kBgOffDo);
+          vec4<T> hi4 = lds_read_tr<T>(lds_ptr(a1) + imm + kBgOffDo);
+          dv[dblk] = mfma(concat<T>(lo4, hi4), pb, dv[dblk]);
+          lo4 = lds_read_tr<T>(lds_ptr(a0) + imm);
+          hi4 = lds_read_tr<T>(lds_ptr(a1) + imm);
+          dk[dblk] = mfma(concat<T>(lo4, hi4), dsb, dk[dblk]);
+        }
+      }
+    }
+    wait_all_vmem();                                   // tile f+1 (DMA) and its statistics have landed
+    if (f + 1 < ntile) write_stats();
+    if (++cg >= G) {
+      cg = 0;
+      j -= 1;
+    }
+    aq ^= kBgQTile;
+    tq[0] ^= kBgQTile;
+    tq[1] ^= kBgQTile;
+    sa ^= kBgStatBytes;
+    ws ^= kBgStatBytes;
+    __syncthreads();
+  }
+
+  if (krow >= lk) return;
+  const int64_t orow = ks.row0 + krow;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const f32x16(&fin)[kBgNB] = which ? dv : dk;
+    const float sc_ = which ? 1.f : p.scale;
+    const Strides st = which ? p.dv_st : p.dk_st;
+    const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head;
+    if (p.kv_f32) {
+      float* ob = (float*)(which ? p.dv : p.dk) + eoff;
+#pragma unroll
+      for (int dblk = 0; dblk < kBgNB; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+            *(f32x4*)(ob + d0) = x;
+          }
+        }
+    } else {
+      store_rows16<T, false, kBgNB>((T*)(which ? p.dv : p.dk) + eoff, fin, sc_, g, p.D, true);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+static inline int big_len(int S, int half) { return half ? (S + 1) / 2 : S; }
+
+template <typename K, typename P>
+static int launch_big(K kernel, const P& p, int64_t nblocks, int smem, std::atomic<unsigned long long>& done, hipStream_t stream) {
+  if (int rc = opt_in_dynamic_lds((const void*)kernel, smem, done)) return rc;
+  if (nblocks <= 0) return kLaunchOk;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(kBgThreads), smem, stream, p);
+  return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
+}
+
+int launch_fwd_big(const FwdParams& p0, int dtype, hipStream_t stream) {
+  static std::atomic<unsigned long long> done_b{0}, done_h{0};
+  FwdParams p = p0;
+  p.nqblk = (big_len(p.Sq, p.q_half) + kBgRows - 1) / kBgRows;
+  const int64_t n = (int64_t)p.nqblk * p.H * p.B;
+  return dtype == 0 ? launch_big(fwd_big_kernel<bf16_t>, p, n, kBgFwdSmem, done_b, stream)
+                    : launch_big(fwd_big_kernel<f16_t>, p, n, kBgFwdSmem, done_h, stream);
+}
+
+int launch_bwd_dq_big(const BwdParams& p0, int dtype, hipStream_t stream) {
+  static std::atomic<unsigned long long> done_b{0}, done_h{0};
+  BwdParams p = p0;
+  p.nqblk = (big_len(p.Sq, p.q_half) + kBgRows - 1) / kBgRows;
+  const int64_t n = (int64_t)p.nqblk * p.H * p.B;
+  return dtype == 0 ? launch_big(dq_big_kernel<bf16_t>, p, n, kBgFwdSmem, done_b, stream)
+                    : launch_big(dq_big_kernel<f16_t>, p, n, kBgFwdSmem, done_h, stream);
+}
+
+int launch_bwd_dkdv_big(const BwdParams& p0, int dtype, hipStream_t stream) {
+  static std::atomic<unsigned long long> done_b{0}, done_h{0};
+  BwdParams p = p0;
+  p.nkblk = (big_len(p.Sk, p.k_half) + kBgRows - 1) / kBgRows;
+  const int64_t n = (int64_t)p.nkblk * p.Hk * p.B;
+  return dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t>, p, n, kBgKvSmem, done_b, stream)
+                    : launch_big(dkdv_big_kernel<f16_t>, p, n, kBgKvSmem, done_h, stream);
+}
+
+}  // namespace rfa

@@ -937,6 +937,7 @@ static int launch_dq_d(const BwdParams& p, hipStream_t stream) {
   return launch_dq_t<T, 64, false, kWin, kDrop>(p, stream);
 }
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
+  if (p.D > 128) return launch_bwd_dq_big(p, dtype, stream);            // rfa_bigd.hip
   if (p.drop_keep < 256) return dtype == 0 ? launch_dq_d<bf16_t, false, true>(p, stream) : launch_dq_d<f16_t, false, true>(p, stream);
   if (windowed(p.causal, p.wl, p.wr)) return dtype == 0 ? launch_dq_d<bf16_t, true, false>(p, stream) : launch_dq_d<f16_t, true, false>(p, stream);
   return dtype == 0 ? launch_dq_d<bf16_t, false, false>(p, stream) : launch_dq_d<f16_t, false, false>(p, stream);
@@ -949,6 +950,7 @@ static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
   return launch_dkdv_t<T, 64, false, false, kWin, false, kDrop>(p, stream);
 }
 int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
+  if (p.D > 128) return launch_bwd_dkdv_big(p, dtype, stream);          // rfa_bigd.hip (rfa_api.cpp: no spill, no 256-key form)
   const bool win = windowed(p.causal, p.wl, p.wr);
   if (p.drop_keep < 256)                          // rfa_api.cpp: dropout calls run the 128-key form without spill / window
     return dtype == 0 ? launch_dkdv_d<bf16_t, false, true>(p, stream) : launch_dkdv_d<f16_t, false, true>(p, stream);

@@ -126,6 +126,11 @@ int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream);
 // 4 waves x 64 rows, one wave per SIMD (rfa_fwd64.hip): D == 128 exactly, no window, no dropout; 256 rows per workgroup
 int launch_fwd64(const FwdParams& p, int dtype, hipStream_t stream);
 int fwd_qrows_per_block();
+// head dims 129 .. 256 (rfa_bigd.hip): same parameter blocks; the launchers set their own nqblk / nkblk
+constexpr int kMaxHeadDim = 256;
+int launch_fwd_big(const FwdParams& p, int dtype, hipStream_t stream);
+int launch_bwd_dq_big(const BwdParams& p, int dtype, hipStream_t stream);
+int launch_bwd_dkdv_big(const BwdParams& p, int dtype, hipStream_t stream);
 
 int launch_preprocess(const PreParams& p, int dtype, hipStream_t stream);
 int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream);

@@ -70,8 +70,10 @@ def test_argument_errors_without_device(built):
     a = _C.FwdArgs()
     a.B, a.H, a.Hk, a.D, a.Sq, a.Sk, a.dtype = 1, 4, 3, 64, 8, 8, 0
     assert lib.rfa_fwd(C.byref(a), None) == -4                # H % Hk
-    a.Hk, a.D = 2, 136
-    assert lib.rfa_fwd(C.byref(a), None) == -3                # head dim
+    a.Hk, a.D = 2, 264
+    assert lib.rfa_fwd(C.byref(a), None) == -3                # head dim: above 256 ...
+    a.D = 132
+    assert lib.rfa_fwd(C.byref(a), None) == -3                # ... or not a multiple of 8
     a.D, a.dtype = 64, 7
     assert lib.rfa_fwd(C.byref(a), None) == -2                # dtype
     a.dtype = 0
