@@ -168,6 +168,22 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 struct DkdvPlan { int wide, nsplit; };
 static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   DkdvPlan pl{0, 1};
+  if (a->D > kHeadDim) {
+    // rfa_bigd.hip: 128-key workgroups that occupy a CU each (one wave per SIMD).  A causal launch is as long as its
+    // heaviest key block, so the tile range of a key block is shared by up to 4 workgroups (fp32 partials, summed by
+    // reduce_kernel) until the launch has about two workgroups per CU, each share with at least 8 tiles of 32 rows.
+    const int64_t sk_ = eff_len(a->Sk, a->k_half), sq_ = eff_len(a->Sq, a->q_half);
+    int64_t kb = (int64_t)a->B * ((sk_ + 127) / 128);
+    if (a->cu_seqlens_k != nullptr && a->total_k > 0) {
+      const int64_t eff = (a->total_k + 127) / 128 + a->B;
+      kb = eff < kb ? eff : kb;
+    }
+    int ns = 1;
+    while (ns < 4 && kb * a->Hk * ns < 448 && sq_ / (ns + 1) >= 256) ++ns;
+    if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
+    pl.nsplit = ns;
+    return pl;
+  }
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if (a->dkdv_form == RFA_DKDV_128 || a->D != kHeadDim || win || a->dropout_p > 0.f) return pl;
   const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);

@@ -13,7 +13,8 @@
 //     256-wide row are 64 (128) registers, the O / dQ accumulators 128, dK + dV 256;
 //   * forward / dQ: a wave owns 32 query rows, 64-key K/V tiles, two LDS stages (128 KiB);
 //     dK/dV: a wave owns 32 keys with K_w, V_w as register B operands, 32-row Q/dO tiles of all query heads of the
-//     K/V group, two LDS stages (64 KiB), dK/dV of the group summed in registers (7-GEMM backward, no dS spill).
+//     K/V group, two LDS stages (64 KiB), dK/dV of the group summed in registers; one launch per tensor (no dS spill:
+//     S is computed three times per backward, 9 GEMM-units for 5).
 // These are coverage kernels, written for clarity: no hand-placed schedules.  Measured rates are in DESIGN.md §3.2.
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
@@ -49,6 +50,32 @@ __device__ __forceinline__ void big_dma_tile(dma_rsrc_t r, int lds_base, int wav
     const int c = P / (R / 4), pc = P % (R / 4);
     dma_load128(r, lds_base + c * R * 256 + pc * 1024, voff[i]);
   }
+}
+
+// kN MFMAs whose A operands come from LDS: operand i is fetched by fa(i) — kReads LDS instructions — kAhead MFMAs
+// before mm(i, a) consumes it.  One wave per SIMD hides nothing by itself: without the read-ahead every MFMA waits
+// out the full LDS latency (measured: 5x).  The sched_group_barriers pin the issue order the loop spells out.
+#ifndef RFA_BG_AHEAD
+#define RFA_BG_AHEAD 4
+#endif
+template <typename T, int kN, int kReads, typename FA, typename MM>
+__device__ __forceinline__ void big_gemm(FA fa, MM mm) {
+  constexpr int kAhead = RFA_BG_AHEAD < kN ? RFA_BG_AHEAD : kN;
+  vec8<T> a[kN];
+#pragma unroll
+  for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
+#pragma unroll
+  for (int i = 0; i < kN; ++i) {
+    if (i + kAhead < kN) a[i + kAhead] = fa(i + kAhead);
+    mm(i, a[i]);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, kReads * kAhead, 0);
+#pragma unroll
+  for (int i = 0; i < kN - kAhead; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
 }
 
 // =====================================================================================
@@ -164,15 +191,12 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
     if (active) {
       f32x16 s[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < kBgNK; ++kk) {
-          const vec8<T> a = lds_read128<T>(lds_ptr(koff[kk & 7]) + kbo + (kk >> 3) * kBgChunkTile + t * 32 * 256);
-          s[t] = mfma(a, qf[kk], s[t]);
-        }
-      }
+      big_gemm<T, 2 * kBgNK, 1>(
+          [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + kbo + ((i >> 3) & 1) * kBgChunkTile + (i >> 4) * 32 * 256); },
+          [&](int i, vec8<T> a) { s[i >> 4] = mfma(a, qf[i & 15], s[i >> 4]); });
       const bool need_mask = (kt0 + kBgKV > lk) || (hi && kt0 + kBgKV - 1 > qw0 + off + wr) || (lo && kt0 < qw0 + 31 + off - wl);
       if (need_mask) {
         const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
@@ -228,20 +252,17 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
               if (!drop_keep(w, e, p.drop_keep)) s[t][4 * mm + e] = 0.f;
           }
       }
+      {
+        vec8<T> pb[4];                                  // [t][ks2]
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          const vec8<T> pb = pack8<T>(s[t], 8 * ks2);
-          const int imm = vbo + (32 * t + 16 * ks2) * 256;
-#pragma unroll
-          for (int dblk = 0; dblk < kBgNB; ++dblk) {
-            const int cimm = imm + (dblk >> 2) * kBgChunkTile;
-            vec4<T> lo4 = lds_read_tr<T>(lds_ptr(voff[dblk & 3][0]) + cimm);
-            vec4<T> hi4 = lds_read_tr<T>(lds_ptr(voff[dblk & 3][1]) + cimm);
-            o[dblk] = mfma(concat<T>(lo4, hi4), pb, o[dblk]);
-          }
-        }
+        for (int x = 0; x < 4; ++x) pb[x] = pack8<T>(s[x >> 1], 8 * (x & 1));
+        big_gemm<T, 4 * kBgNB, 2>(
+            [&](int i) {                                // i = (t, ks2) * 8 + dblk: rows 32 t + 16 ks2 of the V tile
+              const int dblk = i & 7, cimm = vbo + (i >> 3) * 16 * 256 + (dblk >> 2) * kBgChunkTile;
+              return concat<T>(lds_read_tr<T>(lds_ptr(voff[dblk & 3][0]) + cimm), lds_read_tr<T>(lds_ptr(voff[dblk & 3][1]) + cimm));
+            },
+            [&](int i, vec8<T> a) { o[i & 7] = mfma(a, pb[i >> 3], o[i & 7]); });
+      }
     }
     wait_all_vmem();           // tile j+1 has landed
     __syncthreads();
@@ -416,12 +437,12 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < kBgNK; ++kk) {
-          const int fo = (kk >> 3) * kBgChunkTile + t * 32 * 256;
-          s = mfma(lds_read128<T>(lds_ptr(koff[kk & 7]) + kbo + fo), qf[kk], s);
-          dp = mfma(lds_read128<T>(lds_ptr(koff[kk & 7]) + vbo + fo), dof[kk], dp);
-        }
+        big_gemm<T, 2 * kBgNK, 1>(
+            [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + ((i >> 4) ? vbo : kbo) + ((i >> 3) & 1) * kBgChunkTile + t * 32 * 256); },
+            [&](int i, vec8<T> a) {
+              if (i < kBgNK) s = mfma(a, qf[i & 15], s);
+              else dp = mfma(a, dof[i & 15], dp);
+            });
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = fast_exp2(__builtin_fmaf(s[r], c, -L2));
         if (need_mask) {
@@ -444,17 +465,14 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
-#pragma unroll
-        for (int ks2 = 0; ks2 < 2; ++ks2) {
-          const vec8<T> dsb = pack8<T>(s, 8 * ks2);
-          const int imm = kbo + (32 * t + 16 * ks2) * 256;
-#pragma unroll
-          for (int dblk = 0; dblk < kBgNB; ++dblk) {
-            const int cimm = imm + (dblk >> 2) * kBgChunkTile;
-            vec4<T> lo4 = lds_read_tr<T>(lds_ptr(toff[dblk & 3][0]) + cimm);
-            vec4<T> hi4 = lds_read_tr<T>(lds_ptr(toff[dblk & 3][1]) + cimm);
-            dq[dblk] = mfma(concat<T>(lo4, hi4), dsb, dq[dblk]);
-          }
+        {
+          const vec8<T> dsb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
+          big_gemm<T, 2 * kBgNB, 2>(
+              [&](int i) {                              // i = ks2 * 8 + dblk
+                const int dblk = i & 7, cimm = kbo + (32 * t + 16 * (i >> 3)) * 256 + (dblk >> 2) * kBgChunkTile;
+                return concat<T>(lds_read_tr<T>(lds_ptr(toff[dblk & 3][0]) + cimm), lds_read_tr<T>(lds_ptr(toff[dblk & 3][1]) + cimm));
+              },
+              [&](int i, vec8<T> a) { dq[i & 7] = mfma(a, dsb[i >> 3], dq[i & 7]); });
         }
       }
     }
@@ -496,12 +514,31 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
 constexpr int kBgQ = 32;                             // query rows per Q/dO tile
 constexpr int kBgQChunk = kBgQ * 256;                // [32][128] chunk tile: 8 KiB
 constexpr int kBgQTile = 2 * kBgQChunk;              // [32][256]: 16 KiB
-constexpr int kBgOffDo = 2 * kBgQTile;               // dO stages behind the two Q stages
-constexpr int kBgOffStat = 4 * kBgQTile;             // 64 KiB: per stage lse[32] (x -log2 e), delta[32] (x -1)
-constexpr int kBgStatBytes = 2 * kBgQ * 4;
-constexpr int kBgKvSmem = kBgOffStat + 2 * kBgStatBytes;
+constexpr int kBgQStages = 4;                        // LDS ring: three tiles in flight behind the one being computed — one
+                                                     // wave per SIMD and 32 - 48 MFMAs per tile do not cover a DMA round trip
+constexpr int kBgOffDo = kBgQStages * kBgQTile;      // dO stages behind the Q stages (64 KiB)
+constexpr int kBgOffStat = 2 * kBgOffDo;             // 128 KiB: per stage lse[64 slots, 32 used], delta[64 slots]
+constexpr int kBgStatBytes = 2 * 256;
+constexpr int kBgKvSmem = kBgOffStat + kBgQStages * kBgStatBytes;
 
-template <typename T>
+// 4-byte LDS-DMA (buffer_load_dword ... lds): lane L's dword lands at lds_wave_base + 4 L, out-of-range lanes write zeros
+__device__ __forceinline__ void dma_load32(dma_rsrc_t r, int lds_wave_base, int voffset) {
+  asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds"
+               :
+               : "v"(voffset), "s"(r.w), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
+               : "m0");
+}
+// s_waitcnt vmcnt(n), n < 64 (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14])
+template <int n>
+__device__ __forceinline__ void wait_vmem64() {
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
+}
+
+// kWhich: 0 = dV, 1 = dK.  One launch per tensor: with both accumulator sets (2 x 128 registers) next to the K_w / V_w
+// operands (2 x 64) the arch-VGPR half of the register file overflows (hipcc: 290 accumulator-register moves and 80
+// scratch reloads per tile); a launch that owns one tensor fits, at the price of computing S twice (80 instead of
+// 64 MFMAs per tile and wave).
+template <typename T, int kWhich>
 __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
@@ -516,6 +553,9 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const int G = p.H / p.Hk;
   const int hk = idx % p.Hk;
   idx /= p.Hk;
+  const int nsplit = p.nsplit;
+  const int qsplit = idx % nsplit;                    // which share of the key block's tiles (rfa_bwd.hip: kWide)
+  idx /= nsplit;
   const int kblk = idx % p.nkblk;
   const int b = idx / p.nkblk;
   const int h0 = hk * G;
@@ -552,11 +592,13 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const int jt0 = qfirst / kBgQ;
   int jt1 = (qlast + kBgQ - 1) / kBgQ;
   if (jt1 <= jt0) jt1 = jt0;
-  const int jtop = jt1 - 1;
-  const int ntile_q = jtop >= jt0 ? jtop - jt0 + 1 : 0;
+  // this workgroup's tiles: every nsplit-th one counted from the top (interleaved, so that all workgroups walk down
+  // the same tiles at about the same time); the shares' fp32 partials are summed by reduce_kernel (rfa_api.cpp)
+  const int jtop = jt1 - 1 - qsplit;
+  const int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
 
   // this wave's K and V rows: register B operands of S = Q K_w^T and dP = dO V_w^T
-  vec8<T> kwr[kBgNK], vwr[kBgNK];
+  vec8<T> kwr[kBgNK], vwr[kWhich ? kBgNK : 1];
   {
     const int kr = krow < lk ? krow : lk - 1;
     const T* kp = kbase + (int64_t)kr * p.k_st.row;
@@ -565,97 +607,102 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
     for (int kk = 0; kk < kBgNK; ++kk) {
       const int d0 = 16 * kk + 8 * g;
       kwr[kk] = d0 < p.D ? *(const vec8<T>*)(kp + d0) : zero8<T>();
-      vwr[kk] = d0 < p.D ? *(const vec8<T>*)(vp + d0) : zero8<T>();
+      if (kWhich) vwr[kk] = d0 < p.D ? *(const vec8<T>*)(vp + d0) : zero8<T>();
     }
   }
 
   int voff_q[kBgQ / 8], voff_do[kBgQ / 8];
   big_dma_offsets<kBgQ>(wave, lane, (int)p.q_st.row, p.D, voff_q);
   big_dma_offsets<kBgQ>(wave, lane, (int)p.dout_st.row, p.D, voff_do);
-  int dma_stage = 0;
-  int ld_g = 0, ld_j = jtop > 0 ? jtop : 0;       // (head in group, tile) of the next load: tiles from the top down, heads inside
-  float statreg = 0.f;
+  const int ntile = ntile_q * G;
+  // Tiles are walked from the top one down, and for every tile the G heads of the group (the walk order of rfa_bwd.hip:
+  // all workgroups of a launch read the same (tile, head) at about the same time).  Every wave issues the same number
+  // of DMA instructions per tile — 8 tile pieces, plus one statistics row for waves 0 (lse) and 1 (delta) — so that
+  // the counted waits below are exact; loads past the last tile are issued with an empty range (they write zeros).
+  int ld_n = 0, ld_g = 0, ld_j = jtop > 0 ? jtop : 0;
   auto load_tile = [&]() {
-    const int j = ld_j;
+    const bool valid = ld_n < ntile;
+    const int j = valid ? ld_j : 0;
+    const int stage = ld_n & (kBgQStages - 1);
     const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
     const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
-    const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
-    const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
+    const float* statbase = (wave ? dltbase0 + (int64_t)ld_g * p.delta_head : lsebase0 + (int64_t)ld_g * p.lse_head) + j * kBgQ;
+    ++ld_n;
     if (++ld_g >= G) {
       ld_g = 0;
-      ld_j -= 1;
+      ld_j -= nsplit;
     }
     int rows = lq - j * kBgQ;
     rows = rows < kBgQ ? rows : kBgQ;
+    rows = valid && rows > 0 ? rows : 0;
     const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
     const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
     const dma_rsrc_t rq = make_dma_rsrc(qbase + (int64_t)j * kBgQ * p.q_st.row, nq);
     const dma_rsrc_t rdo = make_dma_rsrc(dobase + (int64_t)j * kBgQ * p.dout_st.row, ndo);
-    big_dma_tile<kBgQ>(rq, lds_addr(smem) + dma_stage, wave, voff_q);
-    big_dma_tile<kBgQ>(rdo, lds_addr(smem) + dma_stage + kBgOffDo, wave, voff_do);
-    if (wave == 0) {                              // lanes 0-31: lse of the tile's rows, lanes 32-63: delta
-      const int r = j * kBgQ + l31;
-      statreg = r < lq && r >= 0 ? (g ? dltbase[r] : lsebase[r]) : 0.f;
+    big_dma_tile<kBgQ>(rq, lds_addr(smem) + stage * kBgQTile, wave, voff_q);
+    big_dma_tile<kBgQ>(rdo, lds_addr(smem) + stage * kBgQTile + kBgOffDo, wave, voff_do);
+    if (wave < 2) {
+      const dma_rsrc_t rs = make_dma_rsrc(statbase, rows * 4);
+      dma_load32(rs, lds_addr(smem) + kBgOffStat + stage * kBgStatBytes + wave * 256, lane * 4);
     }
-    dma_stage ^= kBgQTile;
   };
-  int ws = lds_addr(smem) + kBgOffStat + lane * 4;
-  const float stat_scale = g ? -1.f : -kLog2e;
-  auto write_stats = [&]() {
-    if (wave == 0) *(__attribute__((address_space(3))) float*)lds_ptr(ws) = statreg * stat_scale;
+  // tile f + 1 has landed when at most the two youngest tiles' instructions are outstanding
+  auto wait_next_tile = [&]() {
+    if (wave < 2) wait_vmem64<2 * (2 * (kBgQ / 8) + 1)>();
+    else wait_vmem64<2 * 2 * (kBgQ / 8)>();
   };
 
-  int aq = lds_addr(smem) + tile_off(l31, g);                        // Q / dO rows (A operands of S, dP); stage toggled
-  int tq[2];
+  const int aq0 = lds_addr(smem) + tile_off(l31, g);                 // Q / dO rows (A operands of S, dP), stage 0
+  int tq0[2];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) tq[hh] = lds_addr(smem) + tr_off_d<128>(lane, 0, 8 * hh + 4 * g);
-  int sa = lds_addr(smem) + kBgOffStat + 4 * g * 4;                  // row statistics; stage toggled
+  for (int hh = 0; hh < 2; ++hh) tq0[hh] = lds_addr(smem) + tr_off_d<128>(lane, 0, 8 * hh + 4 * g);
+  const int sa0 = lds_addr(smem) + kBgOffStat + 4 * g * 4;           // row statistics, stage 0
 
   const bool drop = p.drop_keep < 256;
   const uint32_t drop_j = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) + (uint32_t)krow : 0u;
   const uint32_t drop_i0 = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
-  f32x16 dk[kBgNB], dv[kBgNB];
+  f32x16 acc[kBgNB];                                   // dK^T or dV^T of this wave's 32 keys
 #pragma unroll
   for (int i = 0; i < kBgNB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  wait_all_vmem();                                     // K_w / V_w: nothing the compiler tracks stays pending into the loop
   load_tile();
-  wait_all_vmem();
-  write_stats();
-  ws ^= kBgStatBytes;
+  load_tile();
+  load_tile();
+  wait_next_tile();                                    // (tile 0)
   __syncthreads();
 
-  const int ntile = ntile_q * G;
   int j = jtop, cg = 0;
   for (int f = 0; f < ntile; ++f) {
-    if (f + 1 < ntile) load_tile();
+    load_tile();                                       // tile f + 3 into the stage of tile f - 1
+    const int so = (f & (kBgQStages - 1)) * kBgQTile;
+    const int aq = aq0 + so, tq[2] = {tq0[0] + so, tq0[1] + so};
+    const int sa = sa0 + (f & (kBgQStages - 1)) * kBgStatBytes;
     const int qs0 = j * kBgQ;
     const bool active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) && !(lo && qs0 + off - wl > kw0 + 31);
     if (active) {
       f32x16 s, dp;
-      f32x4 nd[4];
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]
-        nd[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kBgQ + 8 * jj) * 4);
+        const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = nd[jj][e]; s[4 * jj + e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = kWhich ? -dl[e] : 0.f; s[4 * jj + e] = 0.f; }
       }
+      big_gemm<T, (kWhich ? 2 : 1) * kBgNK, 1>(
+          [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + ((i >> 3) & 1) * kBgQChunk + ((i >> 4) ? kBgOffDo : 0)); },
+          [&](int i, vec8<T> a) {
+            if (i < kBgNK) s = mfma(a, kwr[i & 15], s);
+            else dp = mfma(a, vwr[kWhich ? (i & 15) : 0], dp);
+          });
 #pragma unroll
-      for (int kk = 0; kk < kBgNK; ++kk) {
-        const int fo = (kk >> 3) * kBgQChunk;
-        const int a = aq ^ ((kk & 7) << 5);
-        s = mfma(lds_read128<T>(lds_ptr(a) + fo), kwr[kk], s);
-        dp = mfma(lds_read128<T>(lds_ptr(a) + fo + kBgOffDo), vwr[kk], dp);
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 ls = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * ls[e]));
       }
-      f32x4 l2v[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, l2v[jj][e]));
       const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) || (lo && qs0 + 31 + off - wl > kw0);
       if (need_mask) {
 #pragma unroll
@@ -669,58 +716,52 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
         // the dK/dV kernel's dropout (rfa_bwd.hip): dP = keep ? dO V^T / (1 - p) : 0, dS = P (dP - delta), dV takes keep ? P / (1 - p) : 0
         const uint32_t hkey = drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)(h0 + cg));
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * jj + e;
             const uint32_t w = drop_word(hkey, drop_i0 + (uint32_t)(qs0 + crow(r, g)), drop_j >> 2);
             const bool keep = drop_keep(w, (int)(drop_j & 3u), p.drop_keep);
-            const float dpd = keep ? (dp[r] - nd[jj][e]) * p.drop_scale + nd[jj][e] : nd[jj][e];
-            dp[r] = dpd * s[r];
-            s[r] = keep ? s[r] * p.drop_scale : 0.f;
+            if (kWhich) {
+              const float dpd = keep ? (dp[r] + dl[e]) * p.drop_scale - dl[e] : -dl[e];
+              s[r] = dpd * s[r];                       // dS
+            } else {
+              s[r] = keep ? s[r] * p.drop_scale : 0.f;   // dropped, rescaled P
+            }
           }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dp[r] *= s[r];
-      }
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        const vec8<T> pb = pack8<T>(s, 8 * ks2), dsb = pack8<T>(dp, 8 * ks2);
-#pragma unroll
-        for (int dblk = 0; dblk < kBgNB; ++dblk) {
-          const int imm = 16 * ks2 * 256 + (dblk >> 2) * kBgQChunk;
-          const int a0 = tq[0] ^ ((dblk & 3) << 6), a1 = tq[1] ^ ((dblk & 3) << 6);
-          vec4<T> lo4 = lds_read_tr<T>(lds_ptr(a0) + imm + kBgOffDo);
-          vec4<T> hi4 = lds_read_tr<T>(lds_ptr(a1) + imm + kBgOffDo);
-          dv[dblk] = mfma(concat<T>(lo4, hi4), pb, dv[dblk]);
-          lo4 = lds_read_tr<T>(lds_ptr(a0) + imm);
-          hi4 = lds_read_tr<T>(lds_ptr(a1) + imm);
-          dk[dblk] = mfma(concat<T>(lo4, hi4), dsb, dk[dblk]);
         }
+      } else if (kWhich) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= dp[r];    // dS = P (dP - delta)
+      }
+      // dV^T += dO^T P   /   dK^T += Q^T dS: A operands by transpose reads of the dO / Q tile, B = the packed registers
+      {
+        const vec8<T> pb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
+        big_gemm<T, 2 * kBgNB, 2>(
+            [&](int i) {                                // i = ks2 * 8 + dblk
+              const int dblk = i & 7, imm = 16 * (i >> 3) * 256 + (dblk >> 2) * kBgQChunk + (kWhich ? 0 : kBgOffDo);
+              return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
+            },
+            [&](int i, vec8<T> a) { acc[i & 7] = mfma(a, pb[i >> 3], acc[i & 7]); });
       }
     }
-    wait_all_vmem();                                   // tile f+1 (DMA) and its statistics have landed
-    if (f + 1 < ntile) write_stats();
+    wait_next_tile();
     if (++cg >= G) {
       cg = 0;
-      j -= 1;
+      j -= nsplit;
     }
-    aq ^= kBgQTile;
-    tq[0] ^= kBgQTile;
-    tq[1] ^= kBgQTile;
-    sa ^= kBgStatBytes;
-    ws ^= kBgStatBytes;
     __syncthreads();
   }
+  wait_all_vmem();                                     // (the trailing empty-range loads)
 
   if (krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const f32x16(&fin)[kBgNB] = which ? dv : dk;
+  {
+    constexpr int which = kWhich ? 0 : 1;              // (the 128-wide kernel's naming: 0 = dK, 1 = dV)
     const float sc_ = which ? 1.f : p.scale;
     const Strides st = which ? p.dv_st : p.dk_st;
-    const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head;
+    const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head + (int64_t)qsplit * p.kv_split_stride;
     if (p.kv_f32) {
       float* ob = (float*)(which ? p.dv : p.dk) + eoff;
 #pragma unroll
@@ -731,12 +772,12 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
           if (d0 < p.D) {
             f32x4 x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+            for (int e = 0; e < 4; ++e) x[e] = acc[dblk][4 * jj + e] * sc_;
             *(f32x4*)(ob + d0) = x;
           }
         }
     } else {
-      store_rows16<T, false, kBgNB>((T*)(which ? p.dv : p.dk) + eoff, fin, sc_, g, p.D, true);
+      store_rows16<T, false, kBgNB>((T*)(which ? p.dv : p.dk) + eoff, acc, sc_, g, p.D, true);
     }
   }
 }
@@ -771,12 +812,16 @@ int launch_bwd_dq_big(const BwdParams& p0, int dtype, hipStream_t stream) {
 }
 
 int launch_bwd_dkdv_big(const BwdParams& p0, int dtype, hipStream_t stream) {
-  static std::atomic<unsigned long long> done_b{0}, done_h{0};
+  static std::atomic<unsigned long long> done[4];
   BwdParams p = p0;
   p.nkblk = (big_len(p.Sk, p.k_half) + kBgRows - 1) / kBgRows;
-  const int64_t n = (int64_t)p.nkblk * p.Hk * p.B;
-  return dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t>, p, n, kBgKvSmem, done_b, stream)
-                    : launch_big(dkdv_big_kernel<f16_t>, p, n, kBgKvSmem, done_h, stream);
+  if (p.nsplit < 1) p.nsplit = 1;
+  const int64_t n = (int64_t)p.nkblk * p.Hk * p.B * p.nsplit;
+  int rc = dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t, 0>, p, n, kBgKvSmem, done[0], stream)
+                      : launch_big(dkdv_big_kernel<f16_t, 0>, p, n, kBgKvSmem, done[1], stream);
+  if (rc) return rc;
+  return dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t, 1>, p, n, kBgKvSmem, done[2], stream)
+                    : launch_big(dkdv_big_kernel<f16_t, 1>, p, n, kBgKvSmem, done[3], stream);
 }
 
 }  // namespace rfa
