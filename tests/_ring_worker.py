@@ -136,8 +136,8 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                 cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, rank, W)
                 if cq.tolist() != ref["cu_q"].tolist() or ck.tolist() != ref["cu_k"].tolist() or (sl.start, sl.stop) != tuple(ref["k_slice"]):
                     errs.append(f"{n}: prepare_cu_seqlens mismatch")
-                out, lse, _ = R.llama3_flash_attn_varlen_func(q, k, v, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=c["stride"],
-                                                              local_k_slice=sl, causal=True, **kw)
+                l3_args, l3_kw = (cq.to(dev), ck.to(dev), mq, mk), dict(heads_k_stride=c["stride"], local_k_slice=sl, causal=True, **kw)
+                out, lse, _ = R.llama3_flash_attn_varlen_func(q, k, v, *l3_args, **l3_kw)
             out.backward(do)
             if compiled and kind in ("zigzag", "ring", "zigzag_varlen", "llama3"):
                 # same call without torch.compile: identical bits
@@ -182,6 +182,24 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                 _cmp(f"{n}[r{rank}].kvpacked.dq", pick(q2.grad.cpu()), ref["dq"], tol["grad"], errs)
                 _cmp(f"{n}[r{rank}].kvpacked.dk", pick(kv.grad[:, 0].cpu()), ref["dk"], tol["grad"], errs)
                 _cmp(f"{n}[r{rank}].kvpacked.dv", pick(kv.grad[:, 1].cpu()), ref["dv"], tol["grad"], errs)
+            if kind == "llama3" and not via_reference:
+                # packed entry points (own autograd Functions: K / V are views of the packed tensor, their gradients are
+                # written into one packed gradient)
+                q2 = q.detach().clone().requires_grad_(True)
+                kv = torch.stack([k.detach(), v.detach()], dim=1).requires_grad_(True)
+                out2, lse2, _ = R.llama3_flash_attn_varlen_kvpacked_func(q2, kv, *l3_args, **l3_kw)
+                out2.backward(do)
+                _cmp(f"{n}[r{rank}].kvpacked.out", pick(out2.detach().cpu()), ref["out"], tol["out"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dq", pick(q2.grad.cpu()), ref["dq"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dk", pick(kv.grad[:, 0].cpu()), ref["dk"], tol["grad"], errs)
+                _cmp(f"{n}[r{rank}].kvpacked.dv", pick(kv.grad[:, 1].cpu()), ref["dv"], tol["grad"], errs)
+                if q.shape[1] == k.shape[1]:
+                    qkv = torch.stack([q.detach(), k.detach(), v.detach()], dim=1).requires_grad_(True)
+                    out3, _, _ = R.llama3_flash_attn_varlen_qkvpacked_func(qkv, *l3_args, **l3_kw)
+                    out3.backward(do)
+                    _cmp(f"{n}[r{rank}].qkvpacked.out", pick(out3.detach().cpu()), ref["out"], tol["out"], errs)
+                    for i_, nm in enumerate(("dq", "dk", "dv")):
+                        _cmp(f"{n}[r{rank}].qkvpacked.{nm}", pick(qkv.grad[:, i_].cpu()), ref[nm], tol["grad"], errs)
             if kind == "zigzag":
                 # the kvpacked entry point: K/V travel as ONE packed buffer, dK/dV land in the packed gradient
                 q2 = q.detach().clone().requires_grad_(True)
