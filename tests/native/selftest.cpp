@@ -704,6 +704,9 @@ int main(int argc, char** argv) {
       {"varlen q!=k (llama3 style)", 0, 4, 2, 128, 0, 0, 1, {0, 100, 356}, {0, 300, 812}},
       {"spike keys, non-causal (forces mid-loop rescale)", 1, 2, 2, 128, 300, 520, 0, {}, {}, 1},
       {"spike keys, causal", 1, 3, 3, 128, 640, 640, 1, {}, {}, 1},
+      {"d256 gqa causal (rfa_bigd.hip)", 2, 4, 2, 256, 515, 515, 1, {}, {}},
+      {"d192 rect noncausal (zero-padded second chunk)", 1, 2, 1, 192, 200, 456, 0, {}, {}},
+      {"d256 varlen", 0, 4, 2, 256, 0, 0, 1, {0, 120, 1248, 1500}, {}},
   };
   if (quick) cases.resize(4);
   uint64_t seed = 100;
@@ -713,6 +716,8 @@ int main(int argc, char** argv) {
   run_acc_case(640, 4, 4, 128, 902, true);
   run_bwd_acc_case(384, 4, 2, 128, 903);
   run_bwd_acc_case(300, 3, 3, 128, 904);
+  run_acc_case(512, 4, 2, 256, 905, false);
+  run_bwd_acc_case(384, 4, 2, 256, 906);
 
   if (perf) {
     run_perf(8192, 32, 8, 128, 20);

@@ -67,7 +67,7 @@ def _grads_ok(prefix, got, ref):
 
 
 def test_native_selftest_binary(built):
-    """torch-free C-ABI self test: layout probes + 20 parity groups against oracle/attn_ref.c"""
+    """torch-free C-ABI self test: layout probes + 25 parity groups (head dims 8 ... 256) against oracle/attn_ref.c"""
     exe = built.build_selftest()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     try:  # keep the full log where gpurun merges it back (post-mortem of any failure)
