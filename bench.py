@@ -435,9 +435,11 @@ def main():
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ.setdefault("MASTER_PORT", "29541")
     # one process per GPU over RCCL ("nccl" on ROCm); a single process has nothing to exchange
-    # (libgloo / librccl print connection banners on fd 1: keep stdout for the ONE JSON line)
+    # stdout carries the ONE JSON line and nothing else: librccl / libgloo print version and connection banners on
+    # fd 1 through C stdio buffers that are only flushed at exit (a one-rank RCCL run showed 5 banner lines BEHIND the
+    # JSON line), so fd 1 is pointed at stderr for the whole run and the line is written to the saved descriptor
     sys.stdout.flush()
-    saved_stdout = os.dup(1)
+    real_stdout = os.dup(1)
     os.dup2(2, 1)
     # RFA_BENCH_FORCE_RCCL=1 (tests/test_gpu_rccl_world1.py): a ONE-rank RCCL group with the schedule forced onto its
     # multi-step path — this script's N > 1 branches (RCCL barrier / all_reduce, fixed-count spin-up, comm block)
@@ -446,15 +448,10 @@ def main():
     if forced:
         os.environ["RFA_TEST_FORCE_STEPS"] = "1"
     multi = world > 1 or forced
-    try:
-        if multi:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=0, world_size=1)
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        os.close(saved_stdout)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=0, world_size=1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import ring_flash_attn as R
@@ -755,7 +752,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    os.close(real_stdout)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -33,9 +33,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     saved = os.dup(1)
-    os.dup2(2, 1)                       # RCCL banners go to stderr; stdout carries the one JSON line
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    os.dup2(saved, 1)
+    os.dup2(2, 1)                       # RCCL banners (C stdio, flushed at exit) go to stderr for the whole run;
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # the one JSON line is written to `saved`
     from ring_flash_attn import tuning
     from ring_flash_attn.backend import get_backend
     from ring_flash_attn.utils import comm_stream
@@ -111,7 +110,7 @@ def main():
     if world > 1:
         res["autotune"] = tuning.autotune_zigzag_exchange(None, q, k, v, iters=3, warm=2)
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        os.write(saved, (json.dumps(res) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
 
