@@ -63,5 +63,9 @@ run(1, 8192, 32, 32, 128, True)
 run(1, 8192, 32, 8, 128, False)
 run(1, 8192, 32, 8, 64, True)
 run(1, 8192, 32, 8, 96, True)
+run(1, 8192, 16, 4, 256, True)           # head dims > 128: csrc/rfa_bigd.hip
+run(1, 8192, 16, 4, 256, False)
+run(1, 8192, 20, 5, 192, True)
+run(2, 4096, 8, 8, 256, True)
 run(2, 4096, 16, 16, 128, True)          # BASELINE cfg 2 block shape
 run(1, 8192, 32, 8, 128, True, torch.float16)
