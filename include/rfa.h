@@ -185,7 +185,7 @@ typedef struct {
    * kernel stores dS = P*(dP - delta) of every (32 query x 32 key) block it visits and dQ is computed by a
    * streaming GEMM over those blocks instead of recomputing S and dP (csrc/rfa_dqs.hip).  The contents are
    * only meaningful between the two kernels of one call (or between a RFA_BWD_SKIP_DQ call and the matching
-   * RFA_BWD_SKIP_DKDV call).  Eligible: D == 128, no bounded left window — dense or packed
+   * RFA_BWD_SKIP_DKDV call).  Eligible: D == 128 (or 256), no bounded left window — dense or packed
    * (cu_seqlens: the scratch is then laid out with the extents of the longest sequence, Sq / Sk = max_seqlen). */
   void *ds_scratch;
   int32_t window, window_left, window_right; /* as in rfa_fwd_args (a bounded window_left is not eligible for ds_scratch) */

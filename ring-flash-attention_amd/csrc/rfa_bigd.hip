@@ -216,7 +216,10 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
       mloc = fmaxf(mloc, shfl_xor32(mloc));
       const float mnew = fmaxf(m, mloc);
-      if (!__all(mnew == m)) {
+      // deferred rescale as in rfa_fwd.hip: while no row of the wave grew its max by more than 8 log2 units the stale
+      // max stays (P <= 2^8, exact in fp32) and the 128-register rescale of O — accumulator registers read, scaled
+      // and written back — is skipped
+      if (!__all((mnew - m) * c <= 8.f)) {
         const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
         const float alpha = fast_exp2(m * c - msafe * c);
         m = mnew;
@@ -647,9 +650,14 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
     }
   };
   // tile f + 1 has landed when at most the two youngest tiles' instructions are outstanding
-  auto wait_next_tile = [&]() {
-    if (wave < 2) wait_vmem64<2 * (2 * (kBgQ / 8) + 1)>();
-    else wait_vmem64<2 * 2 * (kBgQ / 8)>();
+  auto wait_next_tile = [&](bool stored) {             // stored: this tile's two dS spill stores are the youngest operations
+    if (stored) {                                      // (vmcnt counts stores too and retires in issue order: rfa_bwd.hip)
+      if (wave < 2) wait_vmem64<2 * (2 * (kBgQ / 8) + 1) + 2>();
+      else wait_vmem64<2 * 2 * (kBgQ / 8) + 2>();
+    } else {
+      if (wave < 2) wait_vmem64<2 * (2 * (kBgQ / 8) + 1)>();
+      else wait_vmem64<2 * 2 * (kBgQ / 8)>();
+    }
   };
 
   const int aq0 = lds_addr(smem) + tile_off(l31, g);                 // Q / dO rows (A operands of S, dP), stage 0
@@ -668,11 +676,21 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+  // dS spill (D == 256, the dK launch; rfa_dqs.hip reads the blocks back — two launches, one per 128-column chunk of
+  // K / dQ — instead of dq_big_kernel recomputing S and dP): block (b, h, qt = tile, kb = key / 32) of the scratch,
+  // slot order and row layout of rfa_bwd.hip's kSpill instances
+  const bool spill = kWhich == 1 && p.ds != nullptr;
+  const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
+  const int ds_nkb = ds_blocks(p.Sk, p.k_half);
+  const int64_t ds_head_bytes = spill ? ds_row_off(ds_blocks(p.Sq, p.q_half), ds_nkb, p.ds_c, 1) * kDsBlockBytes : 0;
+  const char* ds_b = spill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
+  const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kBgRows / 32) + wave);
+
   wait_all_vmem();                                     // K_w / V_w: nothing the compiler tracks stays pending into the loop
   load_tile();
   load_tile();
   load_tile();
-  wait_next_tile();                                    // (tile 0)
+  wait_next_tile(false);                               // (tile 0)
   __syncthreads();
 
   int j = jtop, cg = 0;
@@ -738,6 +756,12 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
       // dV^T += dO^T P   /   dK^T += Q^T dS: A operands by transpose reads of the dO / Q tile, B = the packed registers
       {
         const vec8<T> pb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
+        if (spill) {
+          const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes + (ds_row_off(j, ds_nkb, p.ds_c, 1) + ds_kb) * kDsBlockBytes;
+          const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rb, ds_lane, 0, 2);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[1]), rb, ds_lane + 128, 0, 2);
+        }
         big_gemm<T, 2 * kBgNB, 2>(
             [&](int i) {                                // i = ks2 * 8 + dblk
               const int dblk = i & 7, imm = 16 * (i >> 3) * 256 + (dblk >> 2) * kBgQChunk + (kWhich ? 0 : kBgOffDo);
@@ -746,7 +770,7 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
             [&](int i, vec8<T> a) { acc[i & 7] = mfma(a, pb[i >> 3], acc[i & 7]); });
       }
     }
-    wait_next_tile();
+    wait_next_tile(spill && active);
     if (++cg >= G) {
       cg = 0;
       j -= nsplit;

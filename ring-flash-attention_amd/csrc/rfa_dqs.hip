@@ -259,6 +259,19 @@ static int launch_dq_ds_t(const BwdParams& p, hipStream_t stream) {
 }
 
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream) {
+  if (p.D == 2 * kHeadDim) {
+    // head dim 256 (dS written by rfa_bigd.hip's dK launch): dQ[:, c] = scale dS K[:, c] per 128-column chunk c — the same
+    // kernel twice, on column-offset views of K and dQ
+    for (int c = 0; c < 2; ++c) {
+      BwdParams pc = p;
+      pc.D = kHeadDim;
+      pc.k = (const char*)p.k + (size_t)c * kHeadDim * 2;
+      if (p.dq_acc) pc.dq_acc = p.dq_acc + c * kHeadDim;
+      else pc.dq = (char*)p.dq + (size_t)c * kHeadDim * 2;
+      if (int rc = dtype == 0 ? launch_dq_ds_t<bf16_t>(pc, stream) : launch_dq_ds_t<f16_t>(pc, stream)) return rc;
+    }
+    return kLaunchOk;
+  }
   return dtype == 0 ? launch_dq_ds_t<bf16_t>(p, stream) : launch_dq_ds_t<f16_t>(p, stream);
 }
 

@@ -78,6 +78,45 @@ def test_dense_forward_backward(D, B, Sq, Sk, H, Hk, causal, dtype):
     _grads_ok(f"d{D}.acc2", (dqa / 2, dka / 2, dva / 2), (rdq, rdk, rdv))
 
 
+@pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk", [
+    (1024, 1024, True, 1, 4, 2),      # dense causal: triangular scratch, query range shared by 2 - 4 workgroups
+    (300, 901, True, 2, 2, 2),        # bottom-right aligned, ragged
+    (640, 384, False, 1, 2, 1),       # rectangular scratch
+])
+def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk):
+    """the 5-GEMM backward at D = 256 (the dK launch of rfa_bigd.hip stores dS, rfa_dqs.hip computes dQ from it in two
+    128-column launches) against the oracle, against the 7-GEMM form (dK / dV bit-identical: the same kernel with and
+    without the stores)"""
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    D = 256
+    g = torch.Generator().manual_seed(Sq + Sk)
+    q, k, v = (torch.randn(B, s_, h_, D, generator=g).to(BF) for s_, h_ in ((Sq, H), (Sk, Hk), (Sk, Hk)))
+    do = torch.randn(B, Sq, H, D, generator=g).to(BF)
+    ro, rl, rdq, rdk, rdv = _oracle(q, k, v, do, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    scale = D ** -0.5
+    out, lse = torch.empty_like(qd), torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    res = {}
+    for spill in ("1", "0"):
+        monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv)
+        _grads_ok(f"d256.spill{spill}", (dq, dk, dv), (rdq, rdk, rdv))
+        res[spill] = (dq, dk, dv)
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
+    monkeypatch.setenv("RFA_BWD_DS_SPILL", "1")
+    dqa = torch.zeros(B, Sq, H, D, dtype=torch.float32, device=dev)
+    dka, dva = (torch.empty(B, Sk, Hk, D, dtype=torch.float32, device=dev) for _ in range(2))
+    be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq_acc=dqa, dk_acc=dka, dv_acc=dva, acc_init=True)
+    _grads_ok("d256.spill.acc", (dqa, dka, dva), (rdq, rdk, rdv))
+
+
 def test_forward_merge_of_two_key_halves_equals_one_call():
     """the fused online merge epilogue at D = 256: keys split in two calls (the second one merging into the first's
     accumulators) against one call over all keys"""

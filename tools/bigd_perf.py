@@ -47,7 +47,7 @@ def main():
         delta = torch.empty_like(lse)
         be.bwd_preprocess(do, out, delta)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        os.environ["RFA_BWD_DS_SPILL"] = "0"          # same (7-GEMM) form for every D in this table
+        spill = os.environ.get("RFA_BWD_DS_SPILL", "1")   # (D = 128 and 256 have a 5-GEMM form; RFA_BWD_DS_SPILL=0: 7-GEMM everywhere)
         kw = dict(softmax_scale=sc, causal=True, dq=dq, dk=dk, dv=dv)
         t_b = timed(lambda: be.bwd(do, q, k, v, lse, delta, **kw))
         t_dq = timed(lambda: be.bwd(do, q, k, v, lse, delta, phases=_C.BWD_SKIP_DKDV, **kw))
