@@ -13,9 +13,12 @@
 //     256-wide row are 64 (128) registers, the O / dQ accumulators 128, dK + dV 256;
 //   * forward / dQ: a wave owns 32 query rows, 64-key K/V tiles, two LDS stages (128 KiB);
 //     dK/dV: a wave owns 32 keys with K_w, V_w as register B operands, 32-row Q/dO tiles of all query heads of the
-//     K/V group, two LDS stages (64 KiB), dK/dV of the group summed in registers; one launch per tensor (no dS spill:
-//     S is computed three times per backward, 9 GEMM-units for 5).
-// These are coverage kernels, written for clarity: no hand-placed schedules.  Measured rates are in DESIGN.md §3.2.
+//     K/V group through a 4-stage LDS-DMA ring (130 KiB), dK/dV of the group summed in registers; one launch per
+//     tensor, the tile range of a key block shared by up to 4 workgroups (fp32 partials, reduce_kernel);
+//   * D == 256: the dK launch stores its dS blocks and rfa_dqs.hip computes dQ from them (one launch per 128-column
+//     chunk) — the 5-GEMM form of rfa_bwd.hip; other wide dims recompute S and dP in dq_big_kernel.
+// These are coverage kernels, written for clarity: no hand-placed schedules beyond reading LDS operands ahead of their
+// MFMAs and issuing the next tile's DMA pieces in MFMA shadows.  Measured rates are in DESIGN.md §3.2.
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
 

@@ -200,7 +200,7 @@ class HipBackend:
         else:
             a.dkdv_form, a.dkdv_nsplit = _plan_overrides()
         # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
-        # recomputing S and dP, when the call is eligible (D == 128, whole sequences, dense or packed) and the scratch
+        # recomputing S and dP, when the call is eligible (D == 128 or 256, whole sequences, dense or packed) and the scratch
         # fits (bwd_ds_scratch below); RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
         # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
         if ds_scratch is None and not reduce_only and _spill_enabled():
