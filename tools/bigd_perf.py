@@ -18,8 +18,10 @@ dev = torch.device("cuda:0")
 be = get_backend()
 
 
-def timed(fn, n=10):
-    for _ in range(3):
+def timed(fn, n=40):
+    # (a long warm-up: from idle the chip needs tens of milliseconds of work to reach its sustained clock — 13 launches of
+    #  a 0.8 ms kernel read 20 % slow)
+    for _ in range(60):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
