@@ -67,6 +67,20 @@ __device__ __forceinline__ void big_dma_tile(dma_rsrc_t r, int lds_base, int wav
 #ifndef RFA_BG_AHEAD
 #define RFA_BG_AHEAD 4
 #endif
+// measurement-only switches for dkdv_big_kernel (results are wrong when one is 0): the loop without its DMA pieces /
+// its per-tile wait + barrier / the exp-mask-multiply work / the LDS fragment reads
+#ifndef RFA_BG_X_DMA
+#define RFA_BG_X_DMA 1
+#endif
+#ifndef RFA_BG_X_SYNC
+#define RFA_BG_X_SYNC 1
+#endif
+#ifndef RFA_BG_X_VALU
+#define RFA_BG_X_VALU 1
+#endif
+#ifndef RFA_BG_X_LDS
+#define RFA_BG_X_LDS 1
+#endif
 struct big_no_side {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -765,22 +779,26 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
         for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = kWhich ? -dl[e] : 0.f; s[4 * jj + e] = 0.f; }
       }
       big_gemm<T, (kWhich ? 2 : 1) * kBgNK, 1>(
-          [&](int i) { return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + ((i >> 3) & 1) * kBgQChunk + ((i >> 4) ? kBgOffDo : 0)); },
+          [&](int i) {
+            if (!RFA_BG_X_LDS) return kwr[i & 15];
+            return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + ((i >> 3) & 1) * kBgQChunk + ((i >> 4) ? kBgOffDo : 0));
+          },
           [&](int i, vec8<T> a) {
             if (i < kBgNK) s = mfma(a, kwr[i & 15], s);
             else dp = mfma(a, vwr[kWhich ? (i & 15) : 0], dp);
           },
           [&](int i) {                                  // the next tile's DMA pieces in the shadows of the first MFMAs
-            if (i < kPieces) issue_piece(nxt, i);
+            if (RFA_BG_X_DMA && i < kPieces) issue_piece(nxt, i);
           });
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const f32x4 ls = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * ls[e]));
+        for (int e = 0; e < 4; ++e)
+          if (RFA_BG_X_VALU) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * ls[e]));
       }
       const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) || (lo && qs0 + 31 + off - wl > kw0);
-      if (need_mask) {
+      if (RFA_BG_X_VALU && need_mask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int q = qs0 + crow(r, g);
@@ -823,21 +841,22 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
         big_gemm<T, 2 * kBgNB, 2>(
             [&](int i) {                                // i = ks2 * 8 + dblk
               const int dblk = i & 7, imm = 16 * (i >> 3) * 256 + (dblk >> 2) * kBgQChunk + (kWhich ? 0 : kBgOffDo);
+              if (!RFA_BG_X_LDS) return kwr[i & 15];
               return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
             },
             [&](int i, vec8<T> a) { acc[i & 7] = mfma(a, pb[i >> 3], acc[i & 7]); });
       }
     }
-    if (!active) {
+    if (RFA_BG_X_DMA && !active) {
 #pragma unroll
       for (int i = 0; i < kPieces; ++i) issue_piece(nxt, i);
     }
-    wait_next_tile(spill && active);
+    if (RFA_BG_X_SYNC && RFA_BG_X_DMA) wait_next_tile(spill && active);
     if (++cg >= G) {
       cg = 0;
       j -= nsplit;
     }
-    __syncthreads();
+    if (RFA_BG_X_SYNC) __syncthreads();
   }
   wait_all_vmem();                                     // (the trailing empty-range loads)
 
