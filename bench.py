@@ -334,7 +334,7 @@ def cpu_baseline(hk, full):
     of the schedules (oracle/reference_harness.py).
     Default: ONE whole iteration (all kv-head groups, full S = 8192 causal, fwd+bwd: about 37 s on the 128 threads of
     the pool's EPYC 9575F), after a warm-up pass on a quarter-length problem — nothing extrapolated.  Only when the
-    warm-up predicts more than 75 s for it (a box with few host cores) the sample shrinks to ONE kv-head group scaled by
+    second of two quarter-length warm-up passes predicts more than 120 s for it (a box with few host cores) the sample shrinks to ONE kv-head group scaled by
     the number of groups and is labelled extrapolated — that sample does not fill a many-core host and over-states the
     time (measured: 0.0106 vs 0.0274 it/s).  --cpu-baseline-full forces the whole iteration."""
     from oracle import flash_attn_ref as O
@@ -379,10 +379,11 @@ def cpu_baseline(hk, full):
         sys.stderr.write(f"bench.py: reference-mode CPU baseline unavailable here ({type(e).__name__}); timing the oracle directly\n")
         ref_fn, kind = None, "port"
         once(SEQ // 8, hk, ref_fn)
+    once(SEQ // 4, hk, ref_fn)       # warm-up at the predictor's size (the first large pass pays page faults)
     t0 = time.perf_counter()
-    once(SEQ // 4, hk, ref_fn)       # warm-up and predictor: a causal pass over S / 4 is 1 / 16 of the timed one
+    once(SEQ // 4, hk, ref_fn)       # predictor: a causal pass over S / 4 is 1 / 16 of the timed one
     predicted = 16.0 * (time.perf_counter() - t0)
-    full = full or predicted <= 75.0
+    full = full or predicted <= 120.0
     groups = hk if full else 1
     t0 = time.perf_counter()
     once(SEQ, groups, ref_fn)
@@ -432,7 +433,7 @@ def main():
                     help="N > 1, dense zigzag, exchange 'auto': skip the measured choice between the exchange forms "
                          "(ring_flash_attn.tuning.autotune_zigzag_exchange in the warm-up) and use the shape rule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="always time one whole iteration (the default does unless the host is predicted to need more than 75 s)")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="always time one whole iteration (the default does unless the host is predicted to need more than 120 s)")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
     if args.exchange:
