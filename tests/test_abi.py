@@ -310,6 +310,26 @@ def test_bench_accounting_matches_the_survey():
     assert b.comm_bytes_per_iter("gather", True, 8, 8) == 7 * m + 7 * 2 * m
 
 
+def test_bench_cpu_baseline_times_a_whole_iteration(single_rank_group, monkeypatch):
+    """bench.py's `cpu_baseline` leg (no GPU): by default ONE whole iteration is timed — every kv-head group, nothing
+    extrapolated; the one-group sample is only the fallback for hosts predicted to need more than two minutes; where
+    /root/reference exists the unmodified reference is attempted and, at world size 1 under gloo (it sends dK/dV to
+    its own rank), replaced by the port instead of failing the bench"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    monkeypatch.setattr(b, "SEQ", 512)
+    r = b.cpu_baseline(8, False)
+    assert r["kind"] == "port" and r["extrapolated"] is False and r["sample"].startswith("all 8 kv-head groups")
+    assert r["value"] > 0 and r["unit"] == "iters/sec" and r["cores"] >= 1
+    # a host predicted to be too slow: the bounded one-group sample, labelled as such
+    clock = iter([0.0, 100.0] + [200.0 + i for i in range(8)])
+    monkeypatch.setattr(b.time, "perf_counter", lambda: next(clock))
+    r = b.cpu_baseline(8, False)
+    assert r["extrapolated"] is True and "1 of 8 kv-head groups" in r["sample"]
+
 
 def test_fwd64_owns_its_accumulator_registers(tmp_path):
     """csrc/rfa_fwd64.hip keeps O and Q in accumulator registers a64 .. a255 that only its inline asm touches.  hipcc
