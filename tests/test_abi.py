@@ -325,8 +325,10 @@ def test_bench_cpu_baseline_times_a_whole_iteration(single_rank_group, monkeypat
     assert r["kind"] == "port" and r["extrapolated"] is False and r["sample"].startswith("all 8 kv-head groups")
     assert r["value"] > 0 and r["unit"] == "iters/sec" and r["cores"] >= 1
     # a host predicted to be too slow: the bounded one-group sample, labelled as such
-    clock = iter([0.0, 100.0] + [200.0 + i for i in range(8)])
-    monkeypatch.setattr(b.time, "perf_counter", lambda: next(clock))
+    import types
+
+    clock = iter([0.0, 100.0] + [200.0 + i for i in range(8)])          # (a stub for the module's `time`, not the global one)
+    monkeypatch.setattr(b, "time", types.SimpleNamespace(perf_counter=lambda: next(clock)))
     r = b.cpu_baseline(8, False)
     assert r["extrapolated"] is True and "1 of 8 kv-head groups" in r["sample"]
 
