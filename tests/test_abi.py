@@ -320,17 +320,25 @@ def test_bench_cpu_baseline_times_a_whole_iteration(single_rank_group, monkeypat
     spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    monkeypatch.setattr(b, "SEQ", 512)
-    r = b.cpu_baseline(8, False)
-    assert r["kind"] == "port" and r["extrapolated"] is False and r["sample"].startswith("all 8 kv-head groups")
-    assert r["value"] > 0 and r["unit"] == "iters/sec" and r["cores"] >= 1
-    # a host predicted to be too slow: the bounded one-group sample, labelled as such
+    import sys
     import types
 
-    clock = iter([0.0, 100.0] + [200.0 + i for i in range(8)])          # (a stub for the module's `time`, not the global one)
-    monkeypatch.setattr(b, "time", types.SimpleNamespace(perf_counter=lambda: next(clock)))
-    r = b.cpu_baseline(8, False)
-    assert r["extrapolated"] is True and "1 of 8 kv-head groups" in r["sample"]
+    monkeypatch.setattr(b, "SEQ", 512)
+    saved = dict(sys.modules)            # the reference harness installs the oracle as `flash_attn`: undone below
+    try:
+        r = b.cpu_baseline(8, False)
+        assert r["kind"] == "port" and r["extrapolated"] is False and r["sample"].startswith("all 8 kv-head groups")
+        assert r["value"] > 0 and r["unit"] == "iters/sec" and r["cores"] >= 1
+        # a host predicted to be too slow: the bounded one-group sample, labelled as such
+        clock = iter([0.0, 100.0] + [200.0 + i for i in range(8)])      # (a stub for the module's `time`, not the global one)
+        monkeypatch.setattr(b, "time", types.SimpleNamespace(perf_counter=lambda: next(clock)))
+        r = b.cpu_baseline(8, False)
+        assert r["extrapolated"] is True and "1 of 8 kv-head groups" in r["sample"]
+    finally:
+        for name in list(sys.modules):
+            if name not in saved:
+                del sys.modules[name]
+        sys.modules.update(saved)
 
 
 def test_fwd64_owns_its_accumulator_registers(tmp_path):
