@@ -372,3 +372,29 @@ def test_fwd64_owns_its_accumulator_registers(tmp_path):
     assert not bad, f"the compiler touches the kernel's accumulator registers: {bad[:5]}"
     assert re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text) and \
         all(int(x) == 0 for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)), "scratch in use"
+
+
+def test_wide_head_dim_kernels_fit_the_register_file(tmp_path):
+    """csrc/rfa_bigd.hip runs one wave per SIMD so that a 256-wide row's fragments and accumulators fit the 512-entry
+    register file; a kernel that starts spilling to scratch inside its tile loop would still be correct and several times
+    slower (the one-launch dK + dV form did: DESIGN.md section 3.2).  Audit the generated code: forward and both dK/dV
+    launches without scratch, the dQ kernel within its known 16 spilled registers."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "ring-flash-attention_amd", "csrc", "rfa_bigd.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", str(tmp_path / "x.o"),
+                        "-Wno-inline-asm", "-save-temps=obj"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(tmp_path / [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")][0]).read()
+    kernels = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    seen = {}
+    for name, vgpr, spill in kernels:
+        kind = next((k for k in ("fwd_big", "dq_big", "dkdv_big") if k in name), None)
+        if kind:
+            seen.setdefault(kind, []).append((int(vgpr), int(spill)))
+    assert len(seen.get("fwd_big", [])) == 2 and len(seen.get("dq_big", [])) == 2 and len(seen.get("dkdv_big", [])) == 4, seen
+    assert all(v <= 512 and s == 0 for v, s in seen["fwd_big"] + seen["dkdv_big"]), seen
+    assert all(s <= 32 for _, s in seen["dq_big"]), seen
