@@ -191,7 +191,7 @@ class InStepTimer:
         self.counts = {}          # launches per kind over ALL instrumented steps
 
     def _ev(self):
-        return self.pool.pop()
+        return self.pool.pop() if self.pool else self.hip.event()      # (never fail a run over an empty pool)
 
     # ---- prefix mode (steps that make exactly one fwd, one bwd_preprocess and one bwd call: world size 1): ONE start
     # event in front of the step's first launch and ONE end event behind the forward (prefix 1) or the backward's
