@@ -606,14 +606,20 @@ def main():
     # ---- exchange accounting (N > 1): the same rank-local kernel sequence with the exchange looped back
     if forced:
         result["forced_rccl_world1"] = "N > 1 code path on a one-rank RCCL group (test only, not a measurement)"
+    # (everything below is reporting: the measured line must survive a failure in it — it has only ever run on one GPU —
+    #  so each block records its error under "errors" instead of ending the run; all ranks take the same path)
+    errors = {}
     if multi:
         mode = exchange_mode(kv.detach()[:, :, 0], world, q.detach()) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
+        comp = float("nan")
         rfa_utils.set_loopback((rank, world))
         try:
             for _ in range(2):
                 step()
             counter[0] = 0
             comp = timed(args.steps) / args.steps * 1e3
+        except Exception as e:
+            errors["compute_only"] = f"{type(e).__name__}: {e}"
         finally:
             rfa_utils.set_loopback(None)
         result["comm"] = {
@@ -622,8 +628,8 @@ def main():
             "backend": dist.get_backend(),
             "world_size_observed": dist.get_world_size(),
             "bytes_sent_per_rank_per_iter": comm_bytes_per_iter(mode, _wire_fp32(), world, hk) if wl == "zigzag" else None,
-            "compute_only_ms": comp,
-            "exposed_ms": ms - comp,
+            "compute_only_ms": comp if comp == comp else None,
+            "exposed_ms": (ms - comp) if comp == comp else None,
             "autotune": tune_rep,
             "probe": probe_rep,
             "note": "compute_only = this rank's exact kernel sequence with the exchange looped back to local buffers "
@@ -676,12 +682,17 @@ def main():
                     step()
                     nprof += 1
             torch.cuda.synchronize()
+        except Exception as e:
+            errors["kernels_in_step"] = f"{type(e).__name__}: {e}"
+            single = None
         finally:
             timer.kind, timer.prefix = None, 0
             rfa_backend.set_backend(None)
         spill = os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
         instep = {}
-        if single:
+        if single is None:
+            instep = None
+        elif single:
             per, span_ms = timer.prefix_totals(spill)
             for n, t in per.items():
                 instep[n] = {"avg_launch_ms": t, "launches_per_step": 1.0, "ms_per_step": t}
@@ -697,76 +708,97 @@ def main():
                 instep[n] = {"avg_launch_ms": t[0] / t[1], "launches_per_step": launches, "ms_per_step": t[0] / t[1] * launches}
 
     if rank == 0 and instep is not None:
-        with torch.no_grad():
-            if wl == "zigzag":
-                iso = kernel_breakdown(q.detach(), kv.detach(), dout)
-                f = causal_fwd_flops([SEQ])
+        try:
+            with torch.no_grad():
+                if wl == "zigzag":
+                    iso = kernel_breakdown(q.detach(), kv.detach(), dout)
+                    f = causal_fwd_flops([SEQ])
+                else:
+                    cu_b = torch.tensor(VARLEN_PATTERNS[1], device=dev, dtype=torch.int32)
+                    iso = kernel_breakdown(q.detach(), kv.detach(), dout, cu_b)
+                    f = causal_fwd_flops([b - a for a, b in zip(VARLEN_PATTERNS[1][:-1], VARLEN_PATTERNS[1][1:])])
+            sum_ms = sum(v_["ms_per_step"] for v_ in instep.values())
+            result["kernels_in_step"] = {
+                "ms": {n: round(v_["ms_per_step"], 4) for n, v_ in instep.items()},
+                "launches": {n: v_["launches_per_step"] for n, v_ in instep.items()},
+                "sum_ms": round(sum_ms, 4),
+                "ms_per_step": round(ms, 4),
+                "other_ms": round(ms - sum_ms, 4),
+                "bracket_overhead_ms": round(timer.overhead_ms, 5),
+                # an instrumented step carries two event packets and is not overlapped with its neighbours' launches the
+                # way the timed region's steps are: its launches may span up to 3 % more than the average timed step
+                "consistent": bool(sum_ms <= ms * 1.03),
+                "span_ms": round(span_ms, 4) if span_ms is not None else None,
+                "how": (f"prefix timing inside the real step: one HIP event in front of the step's first launch, one behind "
+                        f"the forward / the backward's first / second kernel, in rotation ({nprof} instrumented steps after the timed "
+                        f"region; inside rfa_bwd through rfa_bwd_args.prof_events); a long launch's ms = difference of two "
+                        f"prefix medians, the two short ones (preprocess, reduction) are bracketed directly, the events' own "
+                        f"cost (an empty prefix) is subtracted; sum = span of a step's launches; other_ms = ms_per_step - sum (the host-side "
+                        f"turn-around between two steps)") if span_ms is not None else
+                       (f"HIP events around ONE launch kind per instrumented step, in rotation (InStepTimer: backend calls of "
+                        f"the public function, rfa_bwd_args.prof_events inside the backward), {nprof} instrumented steps "
+                        f"after the timed region; ms = (average bracketed interval - bracket_overhead_ms, the interval of an "
+                        f"EMPTY bracket at a kernel boundary of the same steps) x launches per step; other_ms = ms_per_step "
+                        f"- sum (host gaps, autograd, grad buffers)"),
+            }
+            if world == 1 and wl == "zigzag":
+                # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
+                # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of S and dP
+                # inside the 7-GEMM dQ kernel is NOT credited)
+                algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+                t_in = {n: instep[n]["avg_launch_ms"] for n in algo if n in instep}
             else:
-                cu_b = torch.tensor(VARLEN_PATTERNS[1], device=dev, dtype=torch.int32)
-                iso = kernel_breakdown(q.detach(), kv.detach(), dout, cu_b)
-                f = causal_fwd_flops([b - a for a, b in zip(VARLEN_PATTERNS[1][:-1], VARLEN_PATTERNS[1][1:])])
-        sum_ms = sum(v_["ms_per_step"] for v_ in instep.values())
-        result["kernels_in_step"] = {
-            "ms": {n: round(v_["ms_per_step"], 4) for n, v_ in instep.items()},
-            "launches": {n: v_["launches_per_step"] for n, v_ in instep.items()},
-            "sum_ms": round(sum_ms, 4),
-            "ms_per_step": round(ms, 4),
-            "other_ms": round(ms - sum_ms, 4),
-            "bracket_overhead_ms": round(timer.overhead_ms, 5),
-            # an instrumented step carries two event packets and is not overlapped with its neighbours' launches the
-            # way the timed region's steps are: its launches may span up to 3 % more than the average timed step
-            "consistent": bool(sum_ms <= ms * 1.03),
-            "span_ms": round(span_ms, 4) if span_ms is not None else None,
-            "how": (f"prefix timing inside the real step: one HIP event in front of the step's first launch, one behind "
-                    f"the forward / the backward's first / second kernel, in rotation ({nprof} instrumented steps after the timed "
-                    f"region; inside rfa_bwd through rfa_bwd_args.prof_events); a long launch's ms = difference of two "
-                    f"prefix medians, the two short ones (preprocess, reduction) are bracketed directly, the events' own "
-                    f"cost (an empty prefix) is subtracted; sum = span of a step's launches; other_ms = ms_per_step - sum (the host-side "
-                    f"turn-around between two steps)") if span_ms is not None else
-                   (f"HIP events around ONE launch kind per instrumented step, in rotation (InStepTimer: backend calls of "
-                    f"the public function, rfa_bwd_args.prof_events inside the backward), {nprof} instrumented steps "
-                    f"after the timed region; ms = (average bracketed interval - bracket_overhead_ms, the interval of an "
-                    f"EMPTY bracket at a kernel boundary of the same steps) x launches per step; other_ms = ms_per_step "
-                    f"- sum (host gaps, autograd, grad buffers)"),
-        }
-        if world == 1 and wl == "zigzag":
-            # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
-            # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of S and dP
-            # inside the 7-GEMM dQ kernel is NOT credited)
-            algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
-            t_in = {n: instep[n]["avg_launch_ms"] for n in algo if n in instep}
-        else:
-            # N > 1 / packed workloads: the step makes several launches of each kernel with different shapes; the
-            # roofline line is this rank's local causal block (step 0 of every world size), timed on its own
-            algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
-            t_in = {n: iso[n] for n in algo}
-        dom = max(t_in, key=lambda n: t_in[n])
-        ach = algo[dom] / (t_in[dom] * 1e-3) / 1e12
-        kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_ds_kernel" if spill else "dq_kernel"}[dom]
-        entry, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
-        result["roofline"] = {
-            "kernel": kn,
-            "launch": "this rank's local causal block (step 0 of every world size)",
-            "bound": "mfma",
-            "achieved": ach,
-            "peak": MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": ach / MFMA_PEAK_TFLOPS,
-            "traffic": entry["hbm_bytes_per_launch"] if entry else None,
-            "traffic_algorithmic": entry.get("algorithmic_bytes") if entry else None,
-            "traffic_handoff": entry.get("handoff_bytes") if entry else None,
-            "traffic_source": note,
-            "avg_launch_ms": t_in[dom],
-            "timed": "in-step" if (world == 1 and wl == "zigzag") else "isolated launches of the local block",
-        }
-        result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t_in.items()}
-        result["kernels_ms_isolated"] = {k2: round(v2, 4) for k2, v2 in iso.items()}
-        result["kernels_tflops"] = {n: algo[n] / (t_in[n] * 1e-3) / 1e12 for n in t_in}
-        bwd_ms = sum(instep[n]["ms_per_step"] for n in instep if n.startswith("bwd"))
-        if world == 1 and wl == "zigzag" and bwd_ms > 0:
-            result["backward_tflops"] = 2.5 * f / (bwd_ms * 1e-3) / 1e12
+                # N > 1 / packed workloads: the step makes several launches of each kernel with different shapes; the
+                # roofline line is this rank's local causal block (step 0 of every world size), timed on its own
+                algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+                t_in = {n: iso[n] for n in algo}
+            dom = max(t_in, key=lambda n: t_in[n])
+            ach = algo[dom] / (t_in[dom] * 1e-3) / 1e12
+            kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_ds_kernel" if spill else "dq_kernel"}[dom]
+            entry, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
+            result["roofline"] = {
+                "kernel": kn,
+                "launch": "this rank's local causal block (step 0 of every world size)",
+                "bound": "mfma",
+                "achieved": ach,
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / MFMA_PEAK_TFLOPS,
+                "traffic": entry["hbm_bytes_per_launch"] if entry else None,
+                "traffic_algorithmic": entry.get("algorithmic_bytes") if entry else None,
+                "traffic_handoff": entry.get("handoff_bytes") if entry else None,
+                "traffic_source": note,
+                "avg_launch_ms": t_in[dom],
+                "timed": "in-step" if (world == 1 and wl == "zigzag") else "isolated launches of the local block",
+            }
+            result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t_in.items()}
+            result["kernels_ms_isolated"] = {k2: round(v2, 4) for k2, v2 in iso.items()}
+            result["kernels_tflops"] = {n: algo[n] / (t_in[n] * 1e-3) / 1e12 for n in t_in}
+            bwd_ms = sum(instep[n]["ms_per_step"] for n in instep if n.startswith("bwd"))
+            if world == 1 and wl == "zigzag" and bwd_ms > 0:
+                result["backward_tflops"] = 2.5 * f / (bwd_ms * 1e-3) / 1e12
+        except Exception as e:
+            errors["roofline"] = f"{type(e).__name__}: {e}"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
+        try:
+            result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
+        except Exception as e:
+            errors["cpu_baseline"] = f"{type(e).__name__}: {e}"
+    if rank == 0 and "roofline" not in result and not args.no_breakdown:
+        # the contract's object, from the isolated launches of the local block when the in-step path failed
+        try:
+            with torch.no_grad():
+                iso = kernel_breakdown(q.detach(), kv.detach(), dout) if wl == "zigzag" else None
+            if iso:
+                f = causal_fwd_flops([SEQ])
+                ach = 2.0 * f / (iso["bwd_dkdv"] * 1e-3) / 1e12
+                result["roofline"] = {"kernel": "dkdv_kernel", "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                                      "avg_launch_ms": iso["bwd_dkdv"], "timed": "isolated launches of the local block (fallback)"}
+        except Exception as e:
+            errors["roofline_fallback"] = f"{type(e).__name__}: {e}"
+    if errors:
+        result["errors"] = errors
 
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
