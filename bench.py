@@ -18,11 +18,18 @@ At every N the line carries
   * `comm`       (N > 1) exchange form, bytes per rank per iteration, and `exposed_ms` = measured step minus
                  the same rank-local kernel sequence with the exchange looped back to local buffers
                  (ring_flash_attn.utils.set_loopback), max over ranks;
-  * `cpu_baseline` (N = 1) the CPU oracle ("port") on a bounded sample of the same workload on this box's
-                 host cores.
-Other workloads of the reference's benchmark suite (benchmark/benchmark_varlen_kvpacked_func.py:14-187):
-  --workload zigzag_varlen | llama3   packed sequences, 8192 tokens per rank, 4 cu_seqlens patterns cycled,
-                                      llama3 with heads_k_stride 4 — BASELINE.json configs[3]/[4] family.
+  * `cpu_baseline` the CPU path on a bounded sample of the same workload on this box's host cores: N = 1 the oracle's
+                 forward / backward ("port"); N > 1 the zigzag schedule over N gloo CPU processes with the oracle
+                 underneath (oracle/cpu_ring_baseline.py: the unmodified reference schedule where /root/reference
+                 exists — "reference" — else this repository's ring-form schedule — "port"), at the largest total
+                 sequence the host finishes within --cpu-baseline-budget-s, stated in `sample`.
+Other rows of the reference's benchmark tables (README.md:82-98):
+  --forward-only                      benchmark_kvpacked_func.py:85-96 (`forward_only`, under torch.no_grad())
+  --workload ring | stripe            the other dense schedules of benchmark_kvpacked_func.py:142-147
+  --workload ring_varlen | zigzag_varlen | llama3
+                                      benchmark/benchmark_varlen_kvpacked_func.py:14-187: packed sequences, 8192 tokens
+                                      per rank, 4 cu_seqlens patterns cycled, llama3 with heads_k_stride 4 —
+                                      BASELINE.json configs[3]/[4] family.
 """
 import argparse
 import hashlib
@@ -56,8 +63,11 @@ def causal_fwd_flops(lengths):
     return sum(4.0 * HEADS * float(L) * float(L) * HEAD_DIM / 2.0 for L in lengths)
 
 
+DENSE = ("zigzag", "ring", "stripe")
+
+
 def fwd_flops_per_gpu(workload, world):
-    if workload == "zigzag":
+    if workload in DENSE:            # (ring / stripe: the average over ranks — their per-rank work is not balanced)
         return causal_fwd_flops([SEQ * world]) / world
     tot = 0.0
     for cu in VARLEN_PATTERNS:      # global sequence lengths = local lengths * world (both varlen workloads)
@@ -322,7 +332,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(hk, full):
+def cpu_baseline(hk, full, fwd_only=False):
     """The reference's CPU path, timed on this box's host cores.
 
     kind "port": the oracle's _flash_attn_forward/_backward called directly — at world size 1 the reference's zigzag
@@ -364,10 +374,16 @@ def cpu_baseline(hk, full):
         qs, ks, vs, dos = q[:, :n, :g * ng], k[:, :n, :ng], v[:, :n, :ng], do[:, :n, :g * ng]
         if fn is not None:
             qq, kk, vv = (t.clone().requires_grad_(True) for t in (qs, ks, vs))
+            if fwd_only:
+                with torch.no_grad():
+                    fn(qq, kk, vv, causal=True)
+                return
             out = fn(qq, kk, vv, causal=True)
             out.backward(dos)
             return
         out, lse, _, _ = O._flash_attn_forward(qs, ks, vs, 0.0, scale, True)
+        if fwd_only:
+            return
         dq, dk, dv = torch.empty_like(qs), torch.empty_like(ks), torch.empty_like(vs)
         O._flash_attn_backward(dos, qs, ks, vs, out, lse, dq, dk, dv, 0.0, scale, True)
 
@@ -397,10 +413,126 @@ def cpu_baseline(hk, full):
         "cpu_model": cpu_model(),
         "kind": kind,
         "extrapolated": not full,
-        "sample": (f"all {hk} kv-head groups, full S={SEQ} causal fwd+bwd, one timed pass after a warm-up ({dt:.2f} s)"
+        "sample": (f"all {hk} kv-head groups, full S={SEQ} causal {'fwd' if fwd_only else 'fwd+bwd'}, one timed pass after a warm-up ({dt:.2f} s)"
                    if full else
-                   f"1 of {hk} kv-head groups ({g} q heads), full S={SEQ} causal fwd+bwd, one timed pass after a "
+                   f"1 of {hk} kv-head groups ({g} q heads), full S={SEQ} causal {'fwd' if fwd_only else 'fwd+bwd'}, one timed pass after a "
                    f"warm-up ({dt:.2f} s), scaled x{hk}"),
+    }
+
+
+class ClockSampler:
+    """best-effort average shader clock during the timed region (MHz): a thread reading the amdgpu sysfs node
+    `freq1_input` (sclk, Hz) of this rank's device every 20 ms.  None where the node is missing or unreadable.  The
+    roofline fraction is quoted against the 2.4 GHz peak; the chip clocks to its power budget (MI355X_MICROARCH.md,
+    "DVFS give-back"), so the line also says at what clock the kernels actually ran."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+
+        self.paths = []
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/freq1_input"))
+        if cards:
+            self.paths = [cards[index % len(cards)]]
+        self.samples, self._stop, self._thr = [], threading.Event(), None
+
+    def _read(self):
+        for p_ in self.paths:
+            try:
+                with open(p_) as f:
+                    return float(f.read().strip()) / 1e6
+            except (OSError, ValueError):
+                return None
+        return None
+
+    def __enter__(self):
+        import threading
+
+        if self.paths and self._read() is not None:
+            def loop():
+                while not self._stop.wait(0.02):
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thr is not None:
+            self._thr.join(timeout=1.0)
+
+    def report(self):
+        if not self.samples:
+            return None
+        return {"avg_mhz": sum(self.samples) / len(self.samples), "min_mhz": min(self.samples), "max_mhz": max(self.samples),
+                "samples": len(self.samples), "peak_mhz": 2400.0,
+                "source": "amdgpu hwmon freq1_input (sclk), 20 ms period, over the timed region"}
+
+
+def cpu_baseline_ring(world, hk, budget_s, fwd_only=False):
+    """N > 1: the zigzag schedule on the host — `world` gloo CPU processes (cores / world threads each) run one
+    forward + backward of zigzag_ring_flash_attn_func with the CPU oracle as their attention arithmetic
+    (oracle/cpu_ring_baseline.py).  The full shape (8192 tokens per rank) costs world^2 times the
+    one-rank iteration, so the timed sample is the largest TOTAL sequence out of {8192 world, 8192, 4096, 2048} that a
+    2048-token probe predicts to finish within `budget_s` (causal attention: time ~ total^2); the sample's shape is
+    stated, nothing is extrapolated, and `tflops` makes samples of different sizes comparable."""
+    import socket
+
+    cores = os.cpu_count() or 1
+    threads = max(1, cores // world)
+
+    def run(total):
+        s_rank = total // world
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            for k_ in ("RFA_ZIGZAG_EXCHANGE", "RFA_TEST_FORCE_STEPS", "RFA_BENCH_FORCE_RCCL", "TORCHELASTIC_RUN_ID"):
+                env.pop(k_, None)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_ring_baseline.py"),
+                                           str(s_rank), str(hk), str(threads), "fwd" if fwd_only else "fwdbwd"],
+                                          env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        outs = [p_.communicate(timeout=max(600.0, 20 * budget_s)) for p_ in procs]
+        for p_, (so, se) in zip(procs, outs):
+            if p_.returncode != 0:
+                raise RuntimeError(f"cpu_ring_baseline rank failed ({p_.returncode}): {se[-800:]}")
+        line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+
+    probe_total = 2048
+    probe = run(probe_total)
+    best, rep = probe_total, probe
+    for total in (SEQ * world, SEQ, SEQ // 2):
+        if total <= probe_total:
+            break
+        if probe["seconds"] * (total / probe_total) ** 2 <= budget_s:
+            best, rep = total, run(total)
+            break
+    flops = (1.0 if fwd_only else 3.5) * causal_fwd_flops([best])
+    full = best == SEQ * world
+    return {
+        "value": 1.0 / rep["seconds"],
+        "unit": "iters/sec",
+        "cores": threads * world,
+        "host_cpus": cores,
+        "cpu_model": cpu_model(),
+        "kind": rep["kind"],
+        "extrapolated": False,
+        "full_shape": full,
+        "tflops": flops / rep["seconds"] / 1e12,
+        "sample": (f"zigzag_ring_flash_attn_func {'fwd' if fwd_only else 'fwd+bwd'} over {world} gloo CPU processes x {threads} threads, "
+                   f"{best // world} tokens per rank (total {best}; the GPU line runs {SEQ} per rank = {SEQ * world}), "
+                   f"h=32 hk={hk} d=128 bf16 causal, one timed iteration after a quarter-length warm-up "
+                   f"({rep['seconds']:.2f} s)" + ("" if full else
+                   f"; the full shape was predicted over the {budget_s:.0f} s budget from a {probe_total}-token probe "
+                   f"({probe['seconds']:.2f} s)")),
     }
 
 
@@ -420,8 +552,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a 0.4 s timed region at N = 1)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kv-heads", type=int, default=8, help="8 = the reference benchmark's GQA; 32 = MHA")
-    ap.add_argument("--workload", default="zigzag", choices=["zigzag", "zigzag_varlen", "llama3"],
-                    help="zigzag = the BASELINE.json headline; the others mirror benchmark_varlen_kvpacked_func.py")
+    ap.add_argument("--workload", default="zigzag", choices=["zigzag", "ring", "stripe", "ring_varlen", "zigzag_varlen", "llama3"],
+                    help="zigzag = the BASELINE.json headline; ring / stripe: the other rows of benchmark_kvpacked_func.py; "
+                         "the *_varlen / llama3 ones mirror benchmark_varlen_kvpacked_func.py")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="time the forward alone under torch.no_grad() (benchmark_kvpacked_func.py:85-96)")
     ap.add_argument("--exchange", default=None, choices=["auto", "gather", "ring"],
                     help="dense zigzag exchange form (default: RFA_ZIGZAG_EXCHANGE or auto)")
     ap.add_argument("--wire", default=None, choices=["io", "fp32"], help="dK/dV dtype on the wire (gather form)")
@@ -434,6 +569,8 @@ def main():
                          "(ring_flash_attn.tuning.autotune_zigzag_exchange in the warm-up) and use the shape rule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="always time one whole iteration (the default does unless the host is predicted to need more than 120 s)")
+    ap.add_argument("--cpu-baseline-budget-s", type=float, default=60.0,
+                    help="N > 1: seconds the timed CPU sample may be predicted to take (picks the total sequence length)")
     ap.add_argument("--no-breakdown", action="store_true")
     args = ap.parse_args()
     if args.exchange:
@@ -478,11 +615,12 @@ def main():
     hk = args.kv_heads
     wl = args.workload
     torch.manual_seed(42 + rank)
-    if wl == "zigzag":
+    if wl in DENSE:
         q = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
         kv = torch.randn(1, SEQ, 2, hk, HEAD_DIM, device=dev, dtype=torch.bfloat16, requires_grad=True)
         dout = torch.randn(1, SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16)
-        fn = R.zigzag_ring_flash_attn_kvpacked_func
+        fn = {"zigzag": R.zigzag_ring_flash_attn_kvpacked_func, "ring": R.ring_flash_attn_kvpacked_func,
+              "stripe": R.stripe_flash_attn_kvpacked_func}[wl]
 
         def call(i):
             return fn(q, kv, causal=True, window_size=(-1, -1), alibi_slopes=None, deterministic=False,
@@ -493,8 +631,8 @@ def main():
         dout = torch.randn(SEQ, HEADS, HEAD_DIM, device=dev, dtype=torch.bfloat16)
         cus = [torch.tensor(c, device=dev, dtype=torch.int32) for c in VARLEN_PATTERNS]
         maxs = [max(b - a for a, b in zip(c[:-1], c[1:])) for c in VARLEN_PATTERNS]
-        if wl == "zigzag_varlen":
-            fn = R.zigzag_ring_flash_attn_varlen_kvpacked_func
+        if wl in ("zigzag_varlen", "ring_varlen"):
+            fn = R.zigzag_ring_flash_attn_varlen_kvpacked_func if wl == "zigzag_varlen" else R.ring_flash_attn_varlen_kvpacked_func
 
             def call(i):
                 j = i % len(cus)
@@ -513,7 +651,14 @@ def main():
 
     counter = [0]
 
+    fwd_only = args.forward_only
+
     def step():
+        if fwd_only:
+            with torch.no_grad():
+                call(counter[0])
+            counter[0] += 1
+            return
         q.grad = None
         kv.grad = None
         out = call(counter[0])
@@ -572,19 +717,22 @@ def main():
     for _ in range(args.warmup):
         step()
     counter[0] = 0
-    elapsed = timed(args.steps)
+    with ClockSampler(local_rank) as clock:
+        elapsed = timed(args.steps)
 
     ms = elapsed / args.steps * 1e3
     its = args.steps / elapsed
-    per_gpu_flops = 3.5 * fwd_flops_per_gpu(wl, world)
-    names = {"zigzag": "zigzag_ring_flash_attn_kvpacked_func", "zigzag_varlen": "zigzag_ring_flash_attn_varlen_kvpacked_func",
-             "llama3": "llama3_flash_attn_varlen_kvpacked_func"}
-    shape = (f"per-rank q=(1,{SEQ},{HEADS},{HEAD_DIM}) kv=(1,{SEQ},2,{hk},{HEAD_DIM})" if wl == "zigzag" else
+    per_gpu_flops = (1.0 if fwd_only else 3.5) * fwd_flops_per_gpu(wl, world)
+    names = {"zigzag": "zigzag_ring_flash_attn_kvpacked_func", "ring": "ring_flash_attn_kvpacked_func",
+             "stripe": "stripe_flash_attn_kvpacked_func", "ring_varlen": "ring_flash_attn_varlen_kvpacked_func",
+             "zigzag_varlen": "zigzag_ring_flash_attn_varlen_kvpacked_func", "llama3": "llama3_flash_attn_varlen_kvpacked_func"}
+    shape = (f"per-rank q=(1,{SEQ},{HEADS},{HEAD_DIM}) kv=(1,{SEQ},2,{hk},{HEAD_DIM})" if wl in DENSE else
              f"per-rank q=({SEQ},{HEADS},{HEAD_DIM}) kv=({SEQ},2,{hk},{HEAD_DIM}), 4 cu_seqlens patterns cycled"
              + (f", heads_k_stride {LLAMA3_HEADS_K_STRIDE}" if wl == "llama3" else ""))
+    passes = "fwd" if fwd_only else "fwd+bwd"
     result = {
-        "metric": "iters/sec fwd+bwd zigzag_ring, seq=8192*ws, h=32, d=128 bf16" if wl == "zigzag"
-                  else f"iters/sec fwd+bwd {wl}, 8192 tokens/rank, h=32, d=128 bf16",
+        "metric": f"iters/sec {passes} zigzag_ring, seq=8192*ws, h=32, d=128 bf16" if wl == "zigzag"
+                  else f"iters/sec {passes} {wl}, 8192 tokens/rank, h=32, d=128 bf16",
         "value": its,
         "unit": "iters/sec",
         "n_gpus": world,
@@ -598,10 +746,12 @@ def main():
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"{names[wl]} fwd+bwd, {shape} bf16 causal, total seq {SEQ * world}",
+            "workload": f"{names[wl]} {passes}, {shape} bf16 causal, total seq {SEQ * world}",
             "kv_heads": hk,
             "world_size": world,
+            "forward_only": fwd_only,
         },
+        "clock": clock.report(),
         "algorithmic_tflops_per_gpu": per_gpu_flops * its / 1e12,
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
     }
@@ -613,7 +763,7 @@ def main():
     #  so each block records its error under "errors" instead of ending the run; all ranks take the same path)
     errors = {}
     if multi:
-        mode = exchange_mode(kv.detach()[:, :, 0], world, q.detach()) if wl == "zigzag" else {"zigzag_varlen": "ring", "llama3": "allgather+reduce_scatter"}[wl]
+        mode = exchange_mode(kv.detach()[:, :, 0], world, q.detach()) if wl == "zigzag" else {"llama3": "allgather+reduce_scatter"}.get(wl, "ring")
         comp = float("nan")
         rfa_utils.set_loopback((rank, world))
         try:
@@ -672,7 +822,7 @@ def main():
             # prefix timing needs a step that launches nothing but one fwd, one preprocess and one backward (the dense
             # zigzag call on one rank; the packed workloads run torch kernels in between — index/fill/add — and keep
             # the bracket form)
-            single = wl == "zigzag" and timer.counts == {"fwd": 4, "bwd_preprocess": 4, "bwd": 4}
+            single = wl in DENSE and timer.counts == {"fwd": 4, "bwd_preprocess": 4, "bwd": 4}
             timer.counts = {}
             counter[0] = 0
             nprof = 0
@@ -713,7 +863,7 @@ def main():
     if rank == 0 and instep is not None:
         try:
             with torch.no_grad():
-                if wl == "zigzag":
+                if wl in DENSE:
                     iso = kernel_breakdown(q.detach(), kv.detach(), dout)
                     f = causal_fwd_flops([SEQ])
                 else:
@@ -744,21 +894,24 @@ def main():
                         f"EMPTY bracket at a kernel boundary of the same steps) x launches per step; other_ms = ms_per_step "
                         f"- sum (host gaps, autograd, grad buffers)"),
             }
-            if world == 1 and wl == "zigzag":
-                # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
-                # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of S and dP
-                # inside the 7-GEMM dQ kernel is NOT credited)
-                algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+            # algorithmic GEMM work per launch (fwd = 4BHS^2D/2, bwd = 2.5 fwd, of which the
+            # dK/dV kernel owns 4 of the 5 backward GEMMs and the dQ kernel the fifth; recomputation of S and dP
+            # inside the 7-GEMM dQ kernel is NOT credited); a forward-only run has the forward launch alone
+            algo = {"fwd": f} if fwd_only else {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
+            in_step_line = world == 1 and wl in DENSE      # one launch of each kernel per step: its in-step time IS the launch's
+            if in_step_line:
                 t_in = {n: instep[n]["avg_launch_ms"] for n in algo if n in instep}
             else:
                 # N > 1 / packed workloads: the step makes several launches of each kernel with different shapes; the
                 # roofline line is this rank's local causal block (step 0 of every world size), timed on its own
-                algo = {"fwd": f, "bwd_dkdv": 2.0 * f, "bwd_dq": 0.5 * f}
                 t_in = {n: iso[n] for n in algo}
             dom = max(t_in, key=lambda n: t_in[n])
             ach = algo[dom] / (t_in[dom] * 1e-3) / 1e12
             kn = {"fwd": "fwd_kernel", "bwd_dkdv": "dkdv_kernel", "bwd_dq": "dq_ds_kernel" if spill else "dq_kernel"}[dom]
-            entry, note = committed_traffic(kn, hk) if wl == "zigzag" else (None, "collected for the headline workload only")
+            entry, note = committed_traffic(kn, hk) if wl in DENSE else (None, "collected for the dense workloads only")
+            # traffic over what the algorithm has to move (inputs once, outputs once): the hand-off the 5-GEMM backward
+            # creates between its two kernels shows up here (13.6x for dkdv_kernel, 26.9x for dq_ds_kernel)
+            t_alg = entry.get("algorithmic_bytes") if entry else None
             result["roofline"] = {
                 "kernel": kn,
                 "launch": "this rank's local causal block (step 0 of every world size)",
@@ -770,28 +923,35 @@ def main():
                 "traffic": entry["hbm_bytes_per_launch"] if entry else None,
                 "traffic_algorithmic": entry.get("algorithmic_bytes") if entry else None,
                 "traffic_handoff": entry.get("handoff_bytes") if entry else None,
+                "traffic_over_algorithmic": (entry["hbm_bytes_per_launch"] / t_alg) if (entry and t_alg) else None,
                 "traffic_source": note,
                 "avg_launch_ms": t_in[dom],
-                "timed": "in-step" if (world == 1 and wl == "zigzag") else "isolated launches of the local block",
+                "timed": "in-step" if in_step_line else "isolated launches of the local block",
+                "clock_avg_mhz": (result["clock"] or {}).get("avg_mhz"),
             }
             result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t_in.items()}
             result["kernels_ms_isolated"] = {k2: round(v2, 4) for k2, v2 in iso.items()}
             result["kernels_tflops"] = {n: algo[n] / (t_in[n] * 1e-3) / 1e12 for n in t_in}
             bwd_ms = sum(instep[n]["ms_per_step"] for n in instep if n.startswith("bwd"))
-            if world == 1 and wl == "zigzag" and bwd_ms > 0:
+            if in_step_line and bwd_ms > 0:
                 result["backward_tflops"] = 2.5 * f / (bwd_ms * 1e-3) / 1e12
         except Exception as e:
             errors["roofline"] = f"{type(e).__name__}: {e}"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and wl in DENSE:
+        # every N carries the CPU path next to the GPU number: N = 1 the oracle directly, N > 1 the
+        # zigzag schedule over N gloo CPU processes (a one-rank forced-RCCL test line runs the two-rank form)
         try:
-            result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full)
+            if multi:
+                result["cpu_baseline"] = cpu_baseline_ring(max(world, 2), hk, args.cpu_baseline_budget_s, fwd_only)
+            else:
+                result["cpu_baseline"] = cpu_baseline(hk, args.cpu_baseline_full, fwd_only)
         except Exception as e:
             errors["cpu_baseline"] = f"{type(e).__name__}: {e}"
     if rank == 0 and "roofline" not in result and not args.no_breakdown:
         # the contract's object, from the isolated launches of the local block when the in-step path failed
         try:
             with torch.no_grad():
-                iso = kernel_breakdown(q.detach(), kv.detach(), dout) if wl == "zigzag" else None
+                iso = kernel_breakdown(q.detach(), kv.detach(), dout) if wl in DENSE else None
             if iso:
                 f = causal_fwd_flops([SEQ])
                 ach = 2.0 * f / (iso["bwd_dkdv"] * 1e-3) / 1e12

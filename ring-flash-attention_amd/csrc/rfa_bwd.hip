@@ -58,7 +58,7 @@
 #define RFA_KV_X_SYNC 1
 #endif
 #ifndef RFA_KV_PRIO
-#define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral)
+#define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
 #endif
 #ifndef RFA_SPILL_AUX
 #define RFA_SPILL_AUX 2      // cache policy bits of the dS spill stores: 2 = nt (streamed once; 0: dkdv +3 %)
@@ -651,8 +651,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   ws ^= kKvStatBytes;
   __syncthreads();
 
-#if RFA_KV_PRIO
+#if RFA_KV_PRIO == 1
   if (par == 0) __builtin_amdgcn_s_setprio(2);
+#elif RFA_KV_PRIO == 2
+  if (wave >= kKvWaves / 2) __builtin_amdgcn_s_setprio(1);   // the half dispatched second (loses every VALU arbitration)
 #endif
   const int ntile = ntile_q * G;
   int j = jtop, cg = 0;

@@ -44,7 +44,14 @@ namespace rfa {
 constexpr int kFwdWaves = RFA_FWD_WAVES;
 constexpr int kFwdThreads = kFwdWaves * 64;
 constexpr int kFwdQRows = kFwdWaves * 32;   // query rows per workgroup
-constexpr int kFwdKV = 64;                  // keys per tile
+#ifndef RFA_FWD_KV
+#define RFA_FWD_KV 64        // keys per tile (64 | 128): 128 halves the barriers / DMA waits per MFMA at twice the LDS and 32 more registers
+#endif
+#ifndef RFA_FWD_YOUNG_PRIO
+#define RFA_FWD_YOUNG_PRIO 0 // 1: waves 4-7 (the half dispatched second, the loser of every VALU arbitration) run at s_setprio 1
+#endif
+constexpr int kFwdKV = RFA_FWD_KV;          // keys per tile
+constexpr int kFwdSub = kFwdKV / 32;        // 32-key sub-tiles per tile
 #ifndef RFA_FWD_STAGES
 #define RFA_FWD_STAGES 2     // LDS ring depth: tile j+STAGES-1 is in flight (DMA) while tile j is computed
 #endif
@@ -236,6 +243,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   wait_all_vmem();          // Q fragment loads too: nothing the compiler tracks may stay pending into the loop
   __syncthreads();
   if (kDist == 2) load_tile(jt0 + 1, std::integral_constant<int, 1>{});   // (rows past the end: descriptor range 0)
+#if RFA_FWD_YOUNG_PRIO
+  if (wave >= kFwdWaves / 2) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // One KV tile.  The LDS stage is a compile-time constant (the tile loop is unrolled by the ring depth),
   // so every LDS address in here is a per-lane table entry plus an instruction immediate.
@@ -253,15 +263,15 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
                         !(lo && kt0 + kFwdKV - 1 < qw0 + off - wl);
     if (active) {
       // ---------------- S^T = K Q^T ----------------
-      f32x16 s[2];
+      f32x16 s[kFwdSub];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < kFwdSub; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
       {
-        // 2 kNK K fragments (2 sub-tiles x kNK k-steps), read kAhead ahead of their MFMA
+        // kFwdSub kNK K fragments (sub-tiles x kNK k-steps), read kAhead ahead of their MFMA
         constexpr int kAhead = RFA_FWD_AHEAD;
-        constexpr int kN = 2 * kNK;
+        constexpr int kN = kFwdSub * kNK;
         vec8<T> a[kN];
         auto fa = [&](int i) { return lds_read128<T>(lds_ptr(koff[i % kNK]) + kbo + (i / kNK) * 32 * kRowBytes); };
 #pragma unroll
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         const int lim = hi ? ((qrow + off + wr < lk - 1) ? qrow + off + wr : lk - 1) : lk - 1;
         const int lim_lo = lo ? qrow + off - wl : -0x40000000;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < kFwdSub; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + 32 * t + crow(r, g);
@@ -299,7 +309,9 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #pragma unroll
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
+      for (int t = 1; t < kFwdSub; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
       mloc = fmaxf(mloc, shfl_xor32(mloc));
       const float mnew = fmaxf(m, mloc);
       // deferred rescale (RFA_FWD_DEFER > 0): while no row of the wave grew its max by more than
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
       // (two fp32 per lane and instruction) — 32 VALU instructions fewer per tile than the element-wise form
       f32x16 psum16;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < kFwdSub; ++t) {
         s[t] = s[t] * c - mc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = fast_exp2(s[t][r]);
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 #else
       float psum = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < kFwdSub; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float pv = fast_exp2(__builtin_fmaf(s[t][r], c, -mc));
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
         // first key position is not a multiple of 4 (wave-uniform)
         const int mis = __builtin_amdgcn_readfirstlane((int)(drop_j0 & 3u));
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < kFwdSub; ++t)
 #pragma unroll
           for (int mm = 0; mm < 4; ++mm) {
             const uint32_t jg = drop_j0 + (uint32_t)(kt0 + 32 * t + 8 * mm + 4 * g);
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
 
       // ---------------- O^T += V^T P^T ----------------
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < kFwdSub; ++t)
 #pragma unroll
         for (int ks2 = 0; ks2 < 2; ++ks2) {
           const vec8<T> pb = pack8<T>(s[t], 8 * ks2);

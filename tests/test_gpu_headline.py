@@ -1,7 +1,9 @@
-"""Full-size checks at the BASELINE.json headline shape (B=1, S=8192, H=32, Hk=8, D=128, bf16,
-causal) through size-independent properties, since the CPU oracle cannot finish the whole tensor
-in seconds:
-  * sampled query rows / key rows recomputed exactly on the host (fp64) — out, lse, dq, dk, dv
+"""Full-size checks at the BASELINE.json headline shape (B=1, S=8192, H=32, Hk=8, D=128, bf16, causal) — the exact
+launch bench.py times (256-key dK/dV form, query-range split 2, triangular dS spill):
+  * ONE WHOLE K/V-HEAD GROUP (4 query heads + their kv head, all 8192 query rows and key rows) against the CPU oracle
+    with every criterion of tests/_tol.py, and against an fp64 computation of the same group ROW BY ROW (relative to
+    each row's own norm) — references that consume nothing the kernels produced (own lse, own out, own delta)
+  * sampled query rows of the other heads recomputed exactly on the host (fp64) — out, lse, dq
   * V = const  =>  out = const  (softmax rows sum to one over 8192 keys)
   * splitting the key range in two and merging with the fused accumulate epilogue == one pass
 """
@@ -28,11 +30,36 @@ def _row(name, i, h, got, ref):
     if path:
         with open(path, "a") as f:
             f.write(f"row        rel-norm {rel:.3e} max_err {mx:.3e} max_ref {ref.abs().max().item():.3e}  headline.{name}[{i},{h}]\n")
-    # (observed on MI355X: <= 2.7e-3; a row whose exact value is zero — dq of a query that sees one key — is held to
-    #  the absolute floor instead)
-    assert err.norm().item() <= 1e-2 * ref.norm().item() + 5e-4 * ref.numel() ** 0.5, \
-        f"{name}[{i},{h}]: relative error of the row {rel:.3e} > 1e-2"
+    # (observed on MI355X: <= 3.3e-3; a row whose exact value is zero — dq of a query that sees one key — is held to
+    #  the absolute floor instead: ROW_FLOOR per element, i.e. 1.1e-3 on the norm of a 128-wide row, 0.6 % of the norm
+    #  of a late causal row (||out|| ~ 0.2))
+    assert err.norm().item() <= ROW_REL * ref.norm().item() + ROW_FLOOR * ref.numel() ** 0.5, \
+        f"{name}[{i},{h}]: relative error of the row {rel:.3e} > {ROW_REL}"
     assert mx <= 2e-3 + 1.6e-2 * ref.abs().max().item(), f"{name}[{i},{h}]: max|err| {mx:.3e}"
+
+
+ROW_REL, ROW_FLOOR = 1e-2, 1e-4
+
+
+def all_rows_relative(name, got, ref):
+    """EVERY row (last dim) of got against the exact fp64 ref, relative to the row's own norm — the criterion of _row,
+    vectorised: ||err_row|| <= ROW_REL ||ref_row|| + ROW_FLOOR sqrt(D)"""
+    import os
+
+    got, ref = got.double().cpu(), ref.double().cpu()
+    assert got.shape == ref.shape, f"{name}: {tuple(got.shape)} vs {tuple(ref.shape)}"
+    en, rn = (got - ref).norm(dim=-1), ref.norm(dim=-1)
+    lim = ROW_REL * rn + ROW_FLOOR * ref.shape[-1] ** 0.5
+    worst = (en / lim).max().item()
+    path = os.environ.get("RFA_TOL_LOG")
+    if path:
+        rel = (en / rn.clamp_min(1e-30))[rn > 10 * ROW_FLOOR * ref.shape[-1] ** 0.5]
+        with open(path, "a") as f:
+            f.write(f"all-rows   worst err/limit {worst:.3f}, worst rel-norm {rel.max().item() if rel.numel() else 0.0:.3e} "
+                    f"over {en.numel()} rows  {name}\n")
+    bad = (en > lim).nonzero()
+    assert bad.numel() == 0, (f"{name}: {bad.shape[0]} of {en.numel()} rows exceed the row-relative bound, first at "
+                              f"{bad[0].tolist()}: ||err|| {en[tuple(bad[0])].item():.3e} vs ||ref|| {rn[tuple(bad[0])].item():.3e}")
 
 
 def _inputs(dev):
@@ -67,23 +94,51 @@ def test_headline_sampled_rows(single_rank_group):
         assert abs(l - lse[0, h, i]) < 1e-3
         _row("out", i, h, out[0, i, h], o)
         dp = vf[0, : i + 1, hk] @ dof[0, i, h]
-        delta = (dof[0, i, h] * out[0, i, h]).sum()
+        delta = (dof[0, i, h] * o).sum()              # (the exact out, not the kernel's)
         ds = p * (dp - delta) * scale
         ref_dq = ds @ kf[0, : i + 1, hk]
         _row("dq", i, h, dq[0, i, h], ref_dq)
-    for j in [0, 1000, S - 1]:
-        hk = int(torch.randint(0, HK, (1,), generator=g))
-        dk, dv = torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
-        for h in range(hk * (H // HK), (hk + 1) * (H // HK)):
-            s = (qf[0, j:, h] @ kf[0, j, hk]) * scale
-            p = torch.exp(s - lse[0, h, j:])
-            dp = dof[0, j:, h] @ vf[0, j, hk]
-            delta = (dof[0, j:, h] * out[0, j:, h]).sum(-1)
-            ds = p * (dp - delta) * scale
-            dk += ds @ qf[0, j:, h]
-            dv += p @ dof[0, j:, h]
-        _row("dk", j, hk, dkv[0, j, 0, hk], dk)
-        _row("dv", j, hk, dkv[0, j, 1, hk], dv)
+
+
+@pytest.mark.parametrize("hk", [5])
+def test_headline_full_tensor_one_kv_group(single_rank_group, hk):
+    """The launch bench.py times, checked on a WHOLE K/V-head group: the 4 query heads of kv head `hk` and that kv head,
+    all 8192 query rows (out, lse, dq) and all 8192 key rows (dk, dv: sums over the 4 heads and every later query).
+    (i) the CPU oracle on exactly that group with every criterion of tests/_tol.py; (ii) an fp64 computation of the
+    group (tests/_fullref.py on the device: rocBLAS + torch, nothing of this library) row by row, relative to each
+    row.  Neither reference reads the kernels' lse / out."""
+    import _fullref
+    import _tol
+    import ring_flash_attn as R
+    from oracle import flash_attn_ref as O
+
+    dev = torch.device("cuda:0")
+    q, kv, do = _inputs(dev)
+    qd, kvd = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+    out, lse, _ = R.zigzag_ring_flash_attn_kvpacked_func(qd, kvd, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    G = H // HK
+    hs = slice(hk * G, (hk + 1) * G)
+    got = dict(out=out[0, :, hs].detach(), lse=lse[0, hs].detach(), dq=qd.grad[0, :, hs],
+               dk=kvd.grad[0, :, 0, hk], dv=kvd.grad[0, :, 1, hk])
+    got = {n: t.float().cpu() for n, t in got.items()}
+    # (i) the oracle, one group
+    qs, ks, vs, dos = q[:, :, hs], kv[:, :, 0, hk:hk + 1], kv[:, :, 1, hk:hk + 1], do[:, :, hs]
+    ro, rl, _, _ = O._flash_attn_forward(qs, ks, vs, 0.0, D ** -0.5, True)
+    rdq, rdk, rdv = torch.empty_like(qs), torch.empty_like(ks), torch.empty_like(vs)
+    O._flash_attn_backward(dos, qs, ks, vs, ro, rl, rdq, rdk, rdv, 0.0, D ** -0.5, True)
+    _tol.compare(f"headline.group{hk}.out", got["out"], ro[0], "out")
+    _tol.compare(f"headline.group{hk}.lse", got["lse"], rl[0], "lse")
+    _tol.compare(f"headline.group{hk}.dq", got["dq"], rdq[0], "grad")
+    _tol.compare(f"headline.group{hk}.dk", got["dk"], rdk[0, :, 0], "grad")
+    _tol.compare(f"headline.group{hk}.dv", got["dv"], rdv[0, :, 0], "grad")
+    # (ii) fp64, every row relative to itself
+    fo, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(qs[0].to(dev), ks[0].to(dev), vs[0].to(dev), dos[0].to(dev))
+    assert (got["lse"].double() - fl.cpu()).abs().max().item() < 2e-5 + 2e-6 * fl.abs().max().item()
+    all_rows_relative(f"headline.group{hk}.out", got["out"], fo)
+    all_rows_relative(f"headline.group{hk}.dq", got["dq"], fdq)
+    all_rows_relative(f"headline.group{hk}.dk", got["dk"], fdk[:, 0])
+    all_rows_relative(f"headline.group{hk}.dv", got["dv"], fdv[:, 0])
 
 
 def test_headline_constant_v_and_split_merge(single_rank_group):
@@ -116,8 +171,8 @@ def test_headline_constant_v_and_split_merge(single_rank_group):
 
 def test_max_length_65536_single_gpu(single_rank_group):
     """The headline's TOTAL sequence (8192 x 8 = 65536) on one GPU: 64-bit addressing, 256 query blocks
-    per head, 1024 KV tiles.  Size-independent checks: sampled rows of out/lse/dq in fp64 on the host,
-    one key row of dk/dv, and constant-V => constant out."""
+    per head, 1024 KV tiles.  Checks: sampled rows of out/lse/dq in fp64 on the host, and the last 5536 key rows of
+    dk/dv (+ the same query rows of dq, lse) of one kv head against a full fp64 computation of that sub-problem."""
     import ring_flash_attn as R
 
     dev = torch.device("cuda:0")
@@ -142,18 +197,19 @@ def test_max_length_65536_single_gpu(single_rank_group):
         assert abs(l - lse[0, h, i]) < 1e-3
         _row("out", i, h, out[0, i, h], o)
         dp = vf[0, : i + 1, hk] @ dof[0, i, h]
-        delta = (dof[0, i, h] * out[0, i, h]).sum()
+        delta = (dof[0, i, h] * o).sum()              # (the exact out, not the kernel's)
         ref_dq = (p * (dp - delta) * scale) @ kf[0, : i + 1, hk]
         _row("dq", i, h, dq[0, i, h], ref_dq)
+    # dk / dv: the key rows 60000 .. 65535 of kv head 1 receive gradient from the queries 60000 .. 65535 of its two query
+    # heads only, so an fp64 computation of THAT sub-problem (5536 bottom-right aligned queries against all keys; own lse,
+    # out and delta — tests/_fullref.py on the device) is their exact reference, row by row
+    import _fullref
+
     j, hk = 60000, 1
-    dk, dv = torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
-    for h in range(hk * (HH // HKK), (hk + 1) * (HH // HKK)):
-        s = (qf[0, j:, h] @ kf[0, j, hk]) * scale
-        p = torch.exp(s - lse[0, h, j:])
-        dp = dof[0, j:, h] @ vf[0, j, hk]
-        delta = (dof[0, j:, h] * out[0, j:, h]).sum(-1)
-        ds = p * (dp - delta) * scale
-        dk += ds @ qf[0, j:, h]
-        dv += p @ dof[0, j:, h]
-    _row("dk", j, hk, dkv[0, j, 0, hk], dk)
-    _row("dv", j, hk, dkv[0, j, 1, hk], dv)
+    hs = slice(hk * (HH // HKK), (hk + 1) * (HH // HKK))
+    _, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(q[0, j:, hs].to(dev), kv[0, :, 0, hk:hk + 1].to(dev),
+                                                          kv[0, :, 1, hk:hk + 1].to(dev), do[0, j:, hs].to(dev))
+    assert (lse[0, hs, j:] - fl.cpu()).abs().max().item() < 2e-5 + 2e-6 * fl.abs().max().item()
+    all_rows_relative("s65536.dq", dq[0, j:, hs], fdq)
+    all_rows_relative("s65536.dk", dkv[0, j:, 0, hk], fdk[j:, 0])
+    all_rows_relative("s65536.dv", dkv[0, j:, 1, hk], fdv[j:, 0])

@@ -33,7 +33,10 @@ def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
     env["RFA_BENCH_FORCE_RCCL"] = "1"
     env["MASTER_PORT"] = str(__import__("conftest").free_port())
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-breakdown", "--workload", workload]
+           "--no-breakdown", "--workload", workload]
+    # the N > 1 line's CPU baseline (the zigzag schedule over gloo CPU processes, oracle/cpu_ring_baseline.py) rides on one
+    # of the cases, with a budget that keeps it to the 2048-token probe
+    cmd += ["--cpu-baseline-budget-s", "1"] if exchange == "gather" else ["--no-cpu-baseline"]
     if exchange:
         cmd += ["--exchange", exchange]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -43,3 +46,7 @@ def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
     d = json.loads(lines[0])
     assert d["forced_rccl_world1"] and d["comm"]["backend"] == "nccl" and d["comm"]["compute_only_ms"] > 0
     assert d["value"] > 0 and d["n_gpus"] == 1
+    if exchange == "gather":
+        cb = d["cpu_baseline"]
+        assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 2 and "gloo CPU processes" in cb["sample"]
+        assert not d.get("errors", {}).get("cpu_baseline")

@@ -231,3 +231,25 @@ def test_dropout_mask_definition():
     # no visible structure along rows, keys or the 4-key word groups
     assert m.mean(dim=(0, 2)).std() < 0.02 and m.mean(dim=(0, 1)).std() < 0.02
     assert abs(m[..., 0::4].mean() - m[..., 3::4].mean()) < 5e-3
+
+
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal", SHAPES)
+def test_blocked_fp64_full_reference_is_the_oracle(B, Sq, Sk, H, Hk, D, causal):
+    """tests/_fullref.py (the full-tensor fp64 reference of the full-size GPU parity tests, blocked over query rows so
+    that it can run a whole kv-head group of the 65536-token configuration on the GPU box's device) against the CPU
+    oracle: same outputs, same empty-row conventions, with a block size that cuts the rows unevenly"""
+    import _fullref
+
+    q, k, v = _rand((B, Sq, H, D), 11), _rand((B, Sk, Hk, D), 12), _rand((B, Sk, Hk, D), 13)
+    do = _rand((B, Sq, H, D), 14)
+    scale = D ** -0.5
+    out, lse, _, _ = R._flash_attn_forward(q.float(), k.float(), v.float(), 0.0, scale, causal)
+    dq, dk, dv = (torch.empty_like(t, dtype=torch.float32) for t in (q, k, v))
+    R._flash_attn_backward(do.float(), q.float(), k.float(), v.float(), out, lse, dq, dk, dv, 0.0, scale, causal)
+    for b in range(B):
+        fo, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(q[b], k[b], v[b], do[b], causal, rows_per_block=37)
+        assert torch.equal(torch.isinf(fl), torch.isinf(lse[b]))
+        fin = torch.isfinite(fl)
+        assert (fl[fin] - lse[b].double()[fin]).abs().max() < 2e-5
+        for got, ref in ((out[b], fo), (dq[b], fdq), (dk[b], fdk), (dv[b], fdv)):
+            assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
