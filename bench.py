@@ -609,6 +609,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import ring_flash_attn as R
+    from ring_flash_attn import config as rfa_config
     from ring_flash_attn import utils as rfa_utils
     from ring_flash_attn.zigzag_ring_flash_attn import exchange_mode, _wire_fp32
 
@@ -684,7 +685,9 @@ def main():
     # tensors of the workload's shapes, max over ranks, same decision on every rank) instead of trusting a default
     # that has never run on this node; a form that fails is disqualified, not fatal.  Untimed, reported in `comm`.
     tune_rep, probe_rep = None, None
-    if multi and wl == "zigzag" and not args.no_autotune and os.environ.get("RFA_ZIGZAG_EXCHANGE", "auto").lower() == "auto":
+    if args.no_autotune:
+        rfa_config.set(autotune=False)           # (the library would otherwise measure on its first multi-rank call)
+    if multi and wl == "zigzag" and not args.no_autotune and rfa_config.get().zigzag_exchange == "auto":
         from ring_flash_attn import tuning
 
         kd, vd = kv.detach()[:, :, 0], kv.detach()[:, :, 1]
@@ -841,7 +844,7 @@ def main():
         finally:
             timer.kind, timer.prefix = None, 0
             rfa_backend.set_backend(None)
-        spill = os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
+        spill = rfa_config.get().bwd_ds_spill
         instep = {}
         if single is None:
             instep = None

@@ -115,7 +115,8 @@ typedef struct {
   /* Dropout (flash_attn's dropout_p; the reference forwards it on the llama3 path,
    * /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:131,135,266).  dropout_p = 0: off.  An attention
    * probability is kept with probability keep/256, keep = round((1 - dropout_p) * 256), and kept ones are scaled by
-   * 1 / (1 - dropout_p); lse is that of the undropped softmax (flash_attn semantics).  The keep mask is a pure
+   * 256 / keep, keep = round((1 - dropout_p) * 256) — the reciprocal of the probability the mask really keeps with, so that
+   * E[dropout(P)] = P for every p —; lse is that of the undropped softmax (flash_attn semantics).  The keep mask is a pure
    * function of (dropout_seed, batch, head_offset + head, q_pos_offset + query position, k_pos_offset + key
    * position) — csrc/rfa_common.hpp: drop_word — where a position is the row inside the dense sequence, or the
    * absolute row of the packed tensor for cu_seqlens input; a rank that holds rows [a, b) of a longer stream passes

@@ -81,7 +81,10 @@ def _mask(sq0: int, nq: int, lq: int, lk: int, causal: bool, device, window=None
 #     word(i, jq) = fmix32((i * 0x9E3779B1) ^ (jq * 0x85EBCA77) ^ head_key),  jq = j >> 2
 #     keep(i, j)  = byte (j & 3) of word(i, j >> 2)  <  round((1 - p) * 256)
 # restated here with numpy uint32 arithmetic.  Semantics are flash_attn's: probabilities entering P V are masked and
-# scaled by 1 / (1 - p), lse is that of the undropped softmax, dP = mask * (dO V^T) / (1 - p), dS = P (dP - delta).
+# rescaled, lse is that of the undropped softmax, dP = mask * (dO V^T) * rescale, dS = P (dP - delta).  The keep
+# probability is quantised to keep / 256 (like flash_attn's uint8 threshold), so the rescale is 256 / keep — the
+# reciprocal of the probability the mask REALLY keeps with — not 1 / (1 - p): E[dropout(P)] = P exactly for every p
+# (with 1 / (1 - p) the expectation was off by up to 0.3 % when p is not a multiple of 1/256).
 # --------------------------------------------------------------------------------------------
 def _fmix32(x):
     import numpy as np
@@ -100,6 +103,12 @@ def drop_threshold(p: float) -> int:
     if not p > 0:
         return 256
     return max(0, min(255, int((1.0 - float(torch.tensor(p, dtype=torch.float32))) * 256.0 + 0.5)))
+
+
+def drop_rescale(p: float) -> float:
+    """256 / keep threshold (rfa_api.cpp: drop_rescale); 0 when nothing is kept"""
+    k = drop_threshold(p)
+    return 256.0 / k if k > 0 else 0.0
 
 
 def dropout_keep(seed: int, p: float, batch: int, heads, i_pos, j_pos) -> torch.Tensor:
@@ -152,7 +161,7 @@ def _fwd_one(q, k, v, scale, causal, window=None, drop=None):
         empty = torch.isinf(l) & (l < 0)
         p = torch.where(empty.unsqueeze(-1), torch.zeros_like(p), p)
         if drop is not None and drop["p"] > 0:
-            p = torch.where(_drop_mask(drop, H, s0, n, Lk), p / (1.0 - drop["p"]), torch.zeros_like(p))
+            p = torch.where(_drop_mask(drop, H, s0, n, Lk), p * drop_rescale(drop["p"]), torch.zeros_like(p))
         out[:, s0:s0 + n] = torch.matmul(p, vf)
         lse[:, s0:s0 + n] = torch.where(empty, torch.full_like(l, float("inf")), l)
     return out.permute(1, 0, 2), lse
@@ -184,7 +193,7 @@ def _bwd_one(dout, q, k, v, out, lse, scale, causal, delta=None, window=None, dr
             pd = p
             if drop is not None and drop["p"] > 0:
                 keep = _drop_mask(drop, H, s0, n, Lk)
-                rp = 1.0 / (1.0 - drop["p"])
+                rp = drop_rescale(drop["p"])
                 dp = torch.where(keep, dp * rp, torch.zeros_like(dp))
                 pd = torch.where(keep, p * rp, torch.zeros_like(p))
             ds = p * (dp - delta[:, s0:s0 + n].unsqueeze(-1)) * scale

@@ -38,6 +38,12 @@ inline unsigned drop_threshold(float p) {
   const int k = (int)((1.f - p) * 256.f + 0.5f);
   return (unsigned)(k < 0 ? 0 : (k > 255 ? 255 : k));      // p > 0 always drops something
 }
+// kept probabilities are rescaled by the reciprocal of the probability the mask REALLY keeps with (keep / 256, the
+// quantised threshold above), not by 1 / (1 - p): E[dropout(P)] = P for every p (oracle/flash_attn_ref.py: drop_rescale)
+inline float drop_rescale(float p) {
+  const unsigned k = drop_threshold(p);
+  return k >= 256u ? 1.f : (k == 0u ? 0.f : 256.f / (float)k);
+}
 inline bool drop_args_ok(float p, int window, int wl, int wr, int causal) {
   if (!(p >= 0.f) || p >= 1.f) return false;
   const bool win = window && (wl >= 0 || (wr >= 0 && !causal));
@@ -119,7 +125,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
   p.drop_keep = drop_threshold(a->dropout_p);
-  p.drop_scale = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_scale = drop_rescale(a->dropout_p);
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   const int rows = fwd_qrows_per_block();
@@ -291,7 +297,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.wr = a->causal ? 0 : ((a->window && a->window_right >= 0) ? a->window_right : -1);
   p.scale = a->softmax_scale;
   p.drop_keep = drop_threshold(a->dropout_p);
-  p.drop_scale = a->dropout_p > 0.f ? 1.f / (1.f - a->dropout_p) : 1.f;
+  p.drop_scale = drop_rescale(a->dropout_p);
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();

@@ -50,3 +50,8 @@ from .adapters import (
 )
 
 __version__ = "0.1.0"
+
+# this library's own knobs (not part of the reference surface): the configuration object (config.py: every RFA_* switch,
+# resolved once) and the source of the per-forward dropout seeds
+from . import config
+from ._common import set_dropout_generator

@@ -101,9 +101,25 @@ def _keep_list(ctx, forward_impl):
     it, never kept for torch.no_grad() calls (no graph), discarded and re-made under activation checkpointing, visible
     to saved-tensor hooks (offloading) — there is no process-global hand-off."""
     if getattr(forward_impl, "keeps_for_backward", False) and any(ctx.needs_input_grad[:3]):
-        keep = []
+        keep = _KeepList()
         return keep, {"keep": keep}
     return None, {}
+
+
+class _KeepList(list):
+    """the tensors a forward hands to its backward, plus the reservation they hold in the process-wide budget of kept
+    bytes (config.kept_budget): released when the backward has run, or with the autograd node"""
+    token = None
+
+
+def _hold_kept(ctx, keep):
+    ctx.kept_token = keep.token if keep else None
+
+
+def _release_kept(ctx):
+    tok = getattr(ctx, "kept_token", None)
+    if tok is not None:
+        tok.release()
 
 
 def _split_kept(ctx, more):
@@ -140,6 +156,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
             )
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
+            _hold_kept(ctx, keep)
             ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale
@@ -160,6 +177,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 softmax_scale=ctx.softmax_scale, dropout_p=ctx.dropout[0], causal=ctx.causal,
                 window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic, **extra,
             )
+            _release_kept(ctx)
             return (dq, dk, dv) + (None,) * (n_lead + 8)
 
     _Fn.__name__ = _Fn.__qualname__ = name
@@ -202,6 +220,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
             )
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
+            _hold_kept(ctx, keep)
             ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
             ctx.lead_rest = tuple(lead[1:]) if n_lead else ()
             ctx.softmax_scale = softmax_scale
@@ -236,6 +255,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 if g.data_ptr() != view.data_ptr():       # schedule returned its own tensor
                     view.copy_(g)
             grads = (dpacked,) if n_packed == 3 else (dq, dpacked)
+            _release_kept(ctx)
             return grads + (None,) * (n_lead + 8)
 
     _PFn.__name__ = _PFn.__qualname__ = name

@@ -60,8 +60,30 @@ def dropout_arg(dropout_p, dropout_seed, q_pos_offset=0, k_pos_offset=0, head_of
     return (float(dropout_p), int(dropout_seed), int(q_pos_offset), int(k_pos_offset), int(head_offset))
 
 
+_DROPOUT_SOURCE = {"generator": None, "group": None, "sync": False}
+
+
+def set_dropout_generator(generator=None, sync_group=None, sync=False):
+    """Where the per-forward dropout seeds come from.  Default (generator=None): torch's default CPU generator, like
+    any torch random op — reproducible under torch.manual_seed, but it advances the stream data loaders and
+    initialisers share, and the documented "sharded mask == unsharded mask" property then needs every rank of a context-
+    parallel group to have seeded alike.  With a dedicated `torch.Generator` the global stream is left alone; with
+    `sync=True` every draw is additionally broadcast from rank 0 of `sync_group` (one 8-byte broadcast per forward), so
+    the ranks agree whatever their seeds (frameworks that seed per rank).  INTEGRATION.md, "Dropout"."""
+    _DROPOUT_SOURCE.update(generator=generator, group=sync_group, sync=bool(sync))
+
+
 def draw_dropout_seed() -> int:
-    """one 62-bit seed from torch's default CPU generator (reproducible under torch.manual_seed; ranks that seeded
-    alike draw alike, which makes the mask of a sharded call equal to the unsharded one — include/rfa.h)"""
+    """one 62-bit seed per forward: from torch's default CPU generator (reproducible under torch.manual_seed; ranks
+    that seeded alike draw alike, which makes the mask of a sharded call equal to the unsharded one — include/rfa.h), or
+    from the source installed with set_dropout_generator()"""
     import torch
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    src = _DROPOUT_SOURCE
+    seed = torch.randint(0, 2 ** 62, (1,), generator=src["generator"])
+    if src["sync"]:
+        import torch.distributed as dist
+
+        if dist.get_backend(src["group"]) != "gloo":           # RCCL broadcasts device memory
+            seed = seed.cuda()
+        dist.broadcast(seed, dist.get_global_rank(src["group"], 0) if src["group"] is not None else 0, group=src["group"])
+    return int(seed.item())

@@ -15,7 +15,7 @@ from typing import Optional
 
 import torch
 
-from . import _C
+from . import _C, config
 
 HALF_FULL, HALF_FRONT, HALF_BACK = _C.HALF_FULL, _C.HALF_FRONT, _C.HALF_BACK
 
@@ -337,40 +337,36 @@ def _set_dropout(a, dropout):
     a.q_pos_offset, a.k_pos_offset, a.head_offset = int(q0), int(k0), int(h0)
 
 
+_FWD_FORMS = {"auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x64": _C.FWD_4x64}
+
+
 def _fwd_form() -> int:
-    """RFA_FWD_FORM = 8x32 | 4x64 (tuning / tests); unset: the library's choice"""
-    import os
-    v = os.environ.get("RFA_FWD_FORM", "").lower()
-    return {"": _C.FWD_AUTO, "auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x64": _C.FWD_4x64}[v]
+    """config.fwd_form (RFA_FWD_FORM = 8x32 | 4x64, tuning / tests); auto: the library's choice"""
+    return _FWD_FORMS[config.get().fwd_form]
 
 
 def _spill_enabled() -> bool:
-    import os
-    return os.environ.get("RFA_BWD_DS_SPILL", "1") not in ("0", "false", "off")
+    return config.get().bwd_ds_spill
 
 
 def _spill_limit() -> int:
-    import os
-    return int(os.environ.get("RFA_DS_SPILL_MAX_BYTES", str(16 << 30)))
+    return config.get().ds_spill_max_bytes
 
 
 def _spill_frac() -> float:
-    import os
-    return float(os.environ.get("RFA_DS_SPILL_MAX_FRAC", "0.5"))
+    return config.get().ds_spill_max_frac
 
 
 def _plan_overrides():
-    """(dkdv_form, dkdv_nsplit) from the tuning / test switches RFA_DKDV_WIDE=0|1 and RFA_DKDV_NSPLIT=n (n > 0 also
-    forces the 256-key form); (AUTO, 0) when unset"""
-    import os
-    wide, ns = os.environ.get("RFA_DKDV_WIDE", ""), os.environ.get("RFA_DKDV_NSPLIT", "")
-    nsplit = int(ns) if ns.strip() else 0
+    """(dkdv_form, dkdv_nsplit) from the tuning / test switches config.dkdv_wide (RFA_DKDV_WIDE=0|1) and
+    config.dkdv_nsplit (RFA_DKDV_NSPLIT=n; n > 0 also forces the 256-key form); (AUTO, 0) when unset"""
+    c = config.get()
     form = _C.DKDV_AUTO
-    if wide.strip() == "0":
+    if c.dkdv_wide == 0:
         form = _C.DKDV_128
-    elif nsplit > 0:
-        form = _C.DKDV_256
-    return form, max(nsplit, 0)
+    elif c.dkdv_nsplit > 0 or c.dkdv_wide == 1:
+        form = _C.DKDV_256 if c.dkdv_nsplit > 0 else _C.DKDV_AUTO
+    return form, c.dkdv_nsplit
 
 
 _SPILL_CHECK_ABOVE = 256 << 20      # bytes: scratch requests up to this size are simply attempted

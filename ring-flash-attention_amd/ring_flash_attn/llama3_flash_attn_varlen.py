@@ -22,10 +22,9 @@ MI355X-first changes:
     integer work on one host copy of `cu_seqlens` instead of ~10 `.item()` syncs; world_size == 1 collapses
     to a single kernel for all heads.
 """
-import os
-
 import torch
 
+from . import config
 from .backend import get_backend
 from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async, single_rank
 from ._api import _check_unsupported, _opaque
@@ -36,7 +35,7 @@ def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world
                          elt_bytes: int) -> int:
     """kv heads per super-group: the largest multiple of heads_k_stride that divides nheads_k and keeps the
     double-buffered gathered K/V below the budget (never smaller than heads_k_stride itself)."""
-    budget = int(os.environ.get("RFA_LLAMA3_GATHER_MAX_BYTES", str(1 << 30)))
+    budget = config.get().llama3_gather_max_bytes
     per_head = 2 * total_k * world * head_dim * elt_bytes          # K and V of one kv head, all ranks
     best = heads_k_stride
     for m in range(1, nheads_k // heads_k_stride + 1):

@@ -19,30 +19,58 @@ bench.py calls both in its warm-up at N > 1 and reports them in its `comm` block
 stand-alone version.  The record is a tuning cache (like a GEMM autotuner's): written once per shape under a lock,
 read-only afterwards; it never holds tensors.
 """
-import os
 import threading
 import time
 
 import torch
 import torch.distributed as dist
 
+from . import config
+
 _LOCK = threading.Lock()
-_TUNED = {}          # (world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
+_TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
 _REPORTS = {}        # same key -> the measurement (for bench.py / logs)
 
 
-def _key(world, q_shape, k_shape, dtype):
+def _group_key(group):
+    """identity of a process group: the sorted global ranks of its members.  A record measured on one group must not
+    decide for another group of the same size (different links; and its peers may never have measured: ranks that
+    disagree about the exchange form hang)"""
+    try:
+        if group is None:
+            return "default"
+        return tuple(sorted(dist.get_process_group_ranks(group)))
+    except Exception:
+        return ("group", id(group))
+
+
+def _key(world, q_shape, k_shape, dtype, group=None):
     B, S, H, D = q_shape
-    return (int(world), int(B), int(S), int(H), int(k_shape[2]), int(D), str(dtype))
+    return (_group_key(group), int(world), int(B), int(S), int(H), int(k_shape[2]), int(D), str(dtype))
 
 
-def lookup(q_shape, k_shape, dtype, world):
-    """the recorded exchange form for this problem, or None"""
-    return _TUNED.get(_key(world, q_shape, k_shape, dtype))
+def lookup(q_shape, k_shape, dtype, world, group=None):
+    """the recorded exchange form for this problem on this group, or None"""
+    return _TUNED.get(_key(world, q_shape, k_shape, dtype, group))
 
 
-def report(q_shape, k_shape, dtype, world):
-    return _REPORTS.get(_key(world, q_shape, k_shape, dtype))
+def report(q_shape, k_shape, dtype, world, group=None):
+    return _REPORTS.get(_key(world, q_shape, k_shape, dtype, group))
+
+
+def can_measure(group, q) -> bool:
+    """the library measures by itself only where the measurement means something and cannot disturb the caller: device
+    tensors on an RCCL group of several ranks (gloo groups are the CPU / shared-GPU test paths), no exchange loopback
+    installed, outside stream capture and outside dynamo tracing"""
+    from . import utils
+
+    if utils._LOOPBACK is not None or not q.is_cuda:
+        return False
+    if dist.get_backend(group) == "gloo" or dist.get_world_size(group) < 2:
+        return False
+    if torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing():
+        return False
+    return True
 
 
 def clear():
@@ -70,7 +98,7 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     from .utils import group_rank_world
 
     world = group_rank_world(group)[1]
-    key = _key(world, q.shape, k.shape, q.dtype)
+    key = _key(world, q.shape, k.shape, q.dtype, group)
     if key in _TUNED:
         return _REPORTS[key]
     dev = q.device
@@ -79,10 +107,8 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     vs = torch.randn(v.shape, device=dev, dtype=torch.float32).to(v.dtype).requires_grad_(True)
     do = torch.randn(q.shape, device=dev, dtype=torch.float32).to(q.dtype)
     ms, failed = {}, {}
-    saved = os.environ.get("RFA_ZIGZAG_EXCHANGE")
-    try:
-        for mode in modes:
-            os.environ["RFA_ZIGZAG_EXCHANGE"] = mode
+    for mode in modes:
+        with config.override(zigzag_exchange=mode), torch.enable_grad():
             ok = 1.0
             try:
                 def one():
@@ -106,11 +132,6 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
             # all ranks agree: a failure anywhere disqualifies the form everywhere
             bad = _max_over_ranks(1.0 - ok, group, dev)
             ms[mode] = float("inf") if bad > 0 else _max_over_ranks(el, group, dev)
-    finally:
-        if saved is None:
-            os.environ.pop("RFA_ZIGZAG_EXCHANGE", None)
-        else:
-            os.environ["RFA_ZIGZAG_EXCHANGE"] = saved
     finite = {m: t for m, t in ms.items() if t != float("inf")}
     if not finite:
         raise RuntimeError(f"autotune_zigzag_exchange: every exchange form failed: {failed}")
@@ -120,7 +141,7 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     with _LOCK:
         _TUNED[key] = chosen
         _REPORTS[key] = rep
-    if os.environ.get("RFA_TUNING_LOG", "0") == "1" and dist.get_rank(group) == 0:
+    if config.get().tuning_log and dist.get_rank(group) == 0:
         import sys
 
         sys.stderr.write(f"ring_flash_attn: zigzag exchange autotune {key}: {rep}\n")

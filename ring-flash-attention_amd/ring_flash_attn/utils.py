@@ -15,12 +15,12 @@ same method names and error behaviour, re-designed for RCCL over xGMI:
   eager TorchScript ops; the schedules in this package do not even call it — they use the
   merge fused into the attention epilogue — it is kept for API parity.
 """
-import os
 from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import config
 from .backend import get_backend
 
 __all__ = ["update_out_and_lse", "RingComm", "AllGatherComm", "flatten_varlen_lse", "unflatten_varlen_lse"]
@@ -110,10 +110,10 @@ def set_loopback(rank_world=None):
 
 
 def single_rank(world_size: int) -> bool:
-    """True when a schedule may collapse to its single-kernel form.  RFA_TEST_FORCE_STEPS=1 (tests only:
+    """True when a schedule may collapse to its single-kernel form.  config.force_steps (RFA_TEST_FORCE_STEPS=1, tests only:
     tests/test_gpu_rccl_world1.py) keeps the multi-step code path — exchange buffers, collectives, side stream,
     fp32 accumulators — even on a one-rank group, which is how the RCCL calls get exercised on a one-GPU box."""
-    return world_size == 1 and os.environ.get("RFA_TEST_FORCE_STEPS", "0") != "1"
+    return world_size == 1 and not config.get().force_steps
 
 
 def group_rank_world(process_group):

@@ -16,7 +16,7 @@ MI355X-first differences:
     dK/dV partials are group-summed straight into the travelling fp32 accumulators, split in
     two phases so the kernels overlap the arrival of those accumulators;
   * world_size == 1 short-circuits to a single kernel writing q.dtype directly;
-  * two exchange forms (RFA_ZIGZAG_EXCHANGE = auto | gather | ring, default auto):
+  * two exchange forms (config.zigzag_exchange / RFA_ZIGZAG_EXCHANGE = auto | gather | ring, default auto):
       ring    the reference's hop-by-hop protocol: per step one batched isend/irecv of K/V (and of the
               travelling fp32 dK/dV accumulators in the backward) to / from the ring neighbours, posted under
               the side stream before the step's kernels and waited after them.  O(S/W) memory per rank.
@@ -30,9 +30,10 @@ MI355X-first differences:
               Cost: scratch of W x (K,V) in the io dtype plus W x (dK,dV) contributions per rank — O(S_total)
               instead of O(S_total/W): 0.27 + 0.27 GB at W = 8, Hk = 8, S = 8192/rank (0.54 GB with fp32
               contributions), 4.3 + 4.3 GB at 128K tokens/rank.
-      auto    gather while that scratch stays below RFA_GATHER_MAX_BYTES (default 4 GiB), ring beyond —
-              long contexts keep ring attention's memory scaling.  The choice depends on shapes only, so
-              every rank takes the same one.
+      auto    the form the library MEASURED to be faster on this group for these shapes (first multi-rank call on an
+              RCCL group: tuning.autotune_zigzag_exchange, a collective decision); without a measurement gather while
+              that scratch stays below config.gather_max_bytes (default 4 GiB), ring beyond — long contexts keep ring
+              attention's memory scaling.  Both rules give every rank the same answer.
     The per-step kernels, their arguments and the merge order are the same in both forms (the forward is
     bit-identical; dK/dV differ by summation order / rounding point only).
   * dK/dV contributions of the gather form travel in the io dtype by default (RFA_DKV_WIRE = io | fp32):
@@ -40,11 +41,9 @@ MI355X-first differences:
     points of the reference, whose flash_attn calls return bf16 block gradients that are then added into
     fp32 buffers (zigzag_ring_flash_attn.py:137-139,164-187) — at half the xGMI bytes of fp32.
 """
-import os
-
 import torch
 
-from . import _C
+from . import _C, config
 from .backend import get_backend
 from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
@@ -57,28 +56,28 @@ def gather_scratch_bytes(k: torch.Tensor, world: int, wire_fp32: bool) -> int:
 
 
 def _wire_fp32() -> bool:
-    mode = os.environ.get("RFA_DKV_WIRE", "io").lower()
-    if mode not in ("io", "bf16", "fp16", "fp32"):
-        raise ValueError(f"RFA_DKV_WIRE must be 'io' or 'fp32', got {mode!r}")
-    return mode == "fp32"
+    return config.get().dkv_wire_fp32
 
 
-def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None) -> str:
-    """RFA_ZIGZAG_EXCHANGE = gather | ring forces a form.  auto (default): the form a measurement on this group
-    recorded for these shapes (tuning.autotune_zigzag_exchange — bench.py runs it in its warm-up), else gather while
-    its O(S_total) scratch stays below RFA_GATHER_MAX_BYTES, ring beyond.  Shapes only: every rank decides alike."""
-    mode = os.environ.get("RFA_ZIGZAG_EXCHANGE", "auto").lower()
-    if mode not in ("auto", "gather", "ring"):
-        raise ValueError(f"RFA_ZIGZAG_EXCHANGE must be 'auto', 'gather' or 'ring', got {mode!r}")
+def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None, group=None, v: torch.Tensor = None) -> str:
+    """config.zigzag_exchange (RFA_ZIGZAG_EXCHANGE) = gather | ring forces a form.  auto (default): the form a
+    MEASUREMENT on this group recorded for these shapes — taken by the library itself on the first multi-rank call of a
+    (group, shapes) pair on an RCCL group (tuning.autotune_zigzag_exchange: fwd + bwd a few times in each form on
+    scratch tensors, max over ranks, so every rank records the same winner; config.autotune / RFA_AUTOTUNE=0 switches
+    it off) — else, nothing measured or measurable, gather while its O(S_total) scratch stays below
+    config.gather_max_bytes, ring beyond: that rule reads shapes only, so every rank decides alike."""
+    cfg = config.get()
+    mode = cfg.zigzag_exchange
     if mode == "auto":
         if q is not None:
             from . import tuning
 
-            tuned = tuning.lookup(q.shape, k.shape, q.dtype, world)
+            tuned = tuning.lookup(q.shape, k.shape, q.dtype, world, group)
+            if tuned is None and v is not None and cfg.autotune and tuning.can_measure(group, q):
+                tuned = tuning.autotune_zigzag_exchange(group, q, k, v)["chosen"]
             if tuned is not None:
                 return tuned
-        limit = int(os.environ.get("RFA_GATHER_MAX_BYTES", str(4 << 30)))
-        mode = "gather" if gather_scratch_bytes(k, world, _wire_fp32()) <= limit else "ring"
+        mode = "gather" if gather_scratch_bytes(k, world, cfg.dkv_wire_fp32) <= cfg.gather_max_bytes else "ring"
     return mode
 
 
@@ -89,12 +88,19 @@ def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None) -> str:
 # posted before the local block and runs beside it — no exchange is left on the critical path of the backward.
 # The buffers are SAVED TENSORS of the autograd node (_api._keep_list): owned by the graph, freed with it, dropped
 # and re-made under activation checkpointing, never created for a forward without a backward.  A forward whose
-# gathered K/V exceed RFA_ZIGZAG_KV_KEEP_BYTES (default 4 GiB per call; RFA_ZIGZAG_KV_KEEP=0: never) keeps
-# nothing: its backward gathers again and keeps the local-block-first order.
-def _kv_keep_limit() -> int:
-    if os.environ.get("RFA_ZIGZAG_KV_KEEP", os.environ.get("RFA_ZIGZAG_KV_CACHE", "1")) == "0":
-        return 0
-    return int(os.environ.get("RFA_ZIGZAG_KV_KEEP_BYTES", str(4 << 30)))
+# gathered K/V exceed config.kv_keep_bytes (default 4 GiB per call; config.kv_keep = False: never), or whose K/V would
+# push the kept buffers of ALL pending backwards of the process over config.kv_keep_total_bytes (default 4 GiB: an
+# L-layer model without activation checkpointing holds L of them — 0.27 GB each at W = 8, Hk = 8, S = 8192 per rank —
+# where the reference saves only the local k / v), keeps nothing: its backward gathers again and keeps the
+# local-block-first order.  The reservation (config.kept_budget) is released when the backward has run or the graph
+# is freed.
+def _try_keep(keep, bufs):
+    if keep is None:
+        return
+    token = config.kept_budget.try_reserve(sum(b_.numel() * b_.element_size() for b_ in bufs))
+    if token is not None:
+        keep.extend(bufs)
+        keep.token = token
 
 
 def _kv_views(bufs, k, world):
@@ -158,13 +164,12 @@ def zigzag_ring_flash_attn_forward(
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, comm.world_size, q) == "gather":
+    if exchange_mode(k, comm.world_size, q, process_group, v) == "gather":
         gather, bufs, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
         gather.wait()
-        if keep is not None and sum(b_.numel() * b_.element_size() for b_ in bufs) <= _kv_keep_limit():
-            keep.extend(bufs)
+        _try_keep(keep, bufs)
         for step in range(1, comm.world_size):
             src = (comm.rank - step) % comm.world_size
             ks, vs = k_all[src], v_all[src]
@@ -242,7 +247,7 @@ def zigzag_ring_flash_attn_backward(
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, kv_comm.world_size, q) == "gather":
+    if exchange_mode(k, kv_comm.world_size, q, process_group, v) == "gather":
         W, rank = kv_comm.world_size, kv_comm.rank
         wire32 = _wire_fp32()
         if kept:

@@ -19,11 +19,9 @@ sequences — one all-gather of K/V beside the local block, every rank's dK/dV c
 c written into slot c (a "front" step fills only the front half of every sequence: the slot is zeroed first),
 one all-to-all, fp32 sum of the W arrivals at the owner (rfa_sum_slots).  Same kernels, same step order.
 """
-import os
-
 import torch
 
-from . import _C
+from . import _C, config
 from .backend import get_backend, HALF_FRONT, HALF_BACK
 from .utils import AllGatherComm, RingComm, all_to_all_async, single_rank
 from ._common import dropout_arg
@@ -31,10 +29,8 @@ from ._api import make_autograd_function, make_varlen_api, _grad_buffers
 
 
 def varlen_exchange_mode() -> str:
-    mode = os.environ.get("RFA_ZIGZAG_VARLEN_EXCHANGE", "ring").lower()
-    if mode not in ("ring", "gather"):
-        raise ValueError(f"RFA_ZIGZAG_VARLEN_EXCHANGE must be 'ring' or 'gather', got {mode!r}")
-    return mode
+    """config.zigzag_varlen_exchange (RFA_ZIGZAG_VARLEN_EXCHANGE): ring | gather"""
+    return config.get().zigzag_varlen_exchange
 
 
 def _gather_kv(process_group, k, v, world):

@@ -45,15 +45,32 @@ def run(rank, W, port, ret):
     counts.append(n_saved(o2))                      # inference: no graph, nothing kept
     o3 = R.zigzag_ring_flash_attn_kvpacked_func(q.detach(), kv.detach(), causal=True)
     counts.append(n_saved(o3))                      # no input needs a gradient
-    # over the per-call limit (or RFA_ZIGZAG_KV_KEEP=0): nothing is kept, the backward gathers again, same gradients
-    for env, val in (("RFA_ZIGZAG_KV_KEEP_BYTES", "16"), ("RFA_ZIGZAG_KV_KEEP", "0")):
-        os.environ[env] = val
-        kv.grad = None
-        o4 = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
-        counts.append(n_saved(o4))
-        o4.sum().backward()
-        counts.append(bool(torch.equal(kv.grad, g_keep)) or float((kv.grad.float() - g_keep.float()).abs().max()) < 2e-2)
-        del os.environ[env]
+    # over the per-call limit (or config.kv_keep = False): nothing is kept, the backward gathers again, same gradients
+    from ring_flash_attn import config
+
+    for field, val in (("kv_keep_bytes", 16), ("kv_keep", False)):
+        with config.override(**{field: val}):
+            kv.grad = None
+            o4 = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+            counts.append(n_saved(o4))
+            o4.sum().backward()
+            counts.append(bool(torch.equal(kv.grad, g_keep)) or float((kv.grad.float() - g_keep.float()).abs().max()) < 2e-2)
+    # the budget over ALL pending backwards of the process (config.kv_keep_total_bytes; ADVICE r3: an L-layer model holds
+    # L kept buffers): with room for one buffer, the first forward keeps, a second one — while the first is still
+    # pending — does not; the reservation returns when the first backward has run
+    assert config.kept_budget.live == 0
+    one = W * kv.numel() * kv.element_size()
+    with config.override(kv_keep_total_bytes=one + one // 2):
+        oa = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+        ob = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+        counts += [n_saved(oa), n_saved(ob), config.kept_budget.live == one]
+        oa.sum().backward()
+        counts.append(config.kept_budget.live == 0)
+        oc = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+        counts.append(n_saved(oc))                  # room again
+        del oa, ob, oc
+        gc.collect()
+        counts.append(config.kept_budget.live == 0)  # a graph that is dropped without a backward returns its share too
     ret[rank] = counts
     dist.barrier()
     dist.destroy_process_group()

@@ -58,12 +58,12 @@ def main(port):
             check(f"{name}.{n}", a, b, 1e-2, 2e-2)
         print("ok", name, flush=True)
 
+    from ring_flash_attn import config
+
     for mode in ("gather", "ring"):
-        os.environ["RFA_ZIGZAG_EXCHANGE"] = mode
         for wire in ("io", "fp32"):
-            os.environ["RFA_DKV_WIRE"] = wire
-            dense_case(R.zigzag_ring_flash_attn_func, f"zigzag[{mode},{wire}]")
-    os.environ.pop("RFA_ZIGZAG_EXCHANGE"); os.environ.pop("RFA_DKV_WIRE")
+            with config.override(zigzag_exchange=mode, dkv_wire_fp32=wire == "fp32"):
+                dense_case(R.zigzag_ring_flash_attn_func, f"zigzag[{mode},{wire}]")
     dense_case(R.ring_flash_attn_func, "ring.causal")
     dense_case(R.ring_flash_attn_func, "ring.full", causal=False)
     dense_case(R.stripe_flash_attn_func, "stripe")
@@ -98,7 +98,7 @@ def main(port):
     varlen_case(R.zigzag_ring_flash_attn_varlen_func, "zigzag_varlen")
     varlen_case(R.ring_flash_attn_varlen_func, "ring_varlen")
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3", llama3=True)
-    os.environ["RFA_LLAMA3_GATHER_MAX_BYTES"] = "0"          # one K/V head group per collective
+    config.set(llama3_gather_max_bytes=0)                    # one K/V head group per collective
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3[unfused]", llama3=True)
     # zigzag_llama3 (all-gather + re-order to stream order + fp32 reduce-scatter)
     q = torch.randn(T, H, D, generator=g).to(BF)

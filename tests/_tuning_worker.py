@@ -34,9 +34,10 @@ def run(rank, W, port, ret, break_gather):
     before = Z.exchange_mode(k, W, q)
     rep = tuning.autotune_zigzag_exchange(None, q, k, v, iters=2, warm=1)
     after = Z.exchange_mode(k, W, q)
-    os.environ["RFA_ZIGZAG_EXCHANGE"] = "ring"
-    forced = Z.exchange_mode(k, W, q)
-    del os.environ["RFA_ZIGZAG_EXCHANGE"]
+    from ring_flash_attn import config
+
+    with config.override(zigzag_exchange="ring"):
+        forced = Z.exchange_mode(k, W, q)
     probe = None if break_gather else tuning.comm_probe(None, torch.device("cpu"), 1 << 16, iters=2, warm=1)
     ret[rank] = dict(before=before, chosen=rep["chosen"], after=after, forced=forced, ms=rep["ms"], failed=rep["failed"],
                      probe=probe, other_shape=Z.exchange_mode(k[:, :32], W, q[:, :32]))

@@ -24,6 +24,36 @@ def free_port():
     return port
 
 
+@pytest.fixture(autouse=True)
+def _rfa_config_follows_the_test_environment(monkeypatch):
+    """The library resolves its RFA_* switches ONCE (ring_flash_attn.config) instead of reading the environment on every
+    call.  Tests steer it through monkeypatch.setenv / delenv: every change of an RFA_* name re-resolves the
+    configuration, and every test starts from the environment as it is then (whatever an earlier test changed in code —
+    config.set(...) — or through the environment is gone)."""
+    try:
+        from ring_flash_attn import config
+    except Exception:            # (tests that never import the package)
+        yield
+        return
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_(name, value, *a, **k):
+        setenv(name, value, *a, **k)
+        if name.startswith("RFA_"):
+            config.reload()
+
+    def delenv_(name, *a, **k):
+        delenv(name, *a, **k)
+        if name.startswith("RFA_"):
+            config.reload()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv_, delenv_
+    config.reload()
+    yield
+    monkeypatch.undo()
+    config.reload()
+
+
 @pytest.fixture(scope="session")
 def single_rank_group():
     """default process group of world size 1 (the public API needs torch.distributed initialised)."""

@@ -195,6 +195,7 @@ def test_config3_headline_w8_at_its_stated_shape(monkeypatch, mode):
     fo, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(q[0, :, hs].to(dev), k[0, :, hk:hk + 1].to(dev),
                                                             v[0, :, hk:hk + 1].to(dev), do[0, :, hs].to(dev))
     fo, fl, fdq, fdk, fdv = (t.cpu() for t in (fo, fl, fdq, fdk, fdv))
+    dq_allow = _fullref.attention_fwd_bwd_fp64.dq_delta_allowance.cpu()
     torch.cuda.empty_cache()
     _tol.compare(f"cfg3.{mode}.group{hk}.out", out[0, :, hs], fo, "out_ring")
     _tol.compare(f"cfg3.{mode}.group{hk}.lse", lse[0, hs], fl, "lse_ring")
@@ -202,7 +203,7 @@ def test_config3_headline_w8_at_its_stated_shape(monkeypatch, mode):
     _tol.compare(f"cfg3.{mode}.group{hk}.dk", dk[0, :, hk], fdk[:, 0], "grad_ring")
     _tol.compare(f"cfg3.{mode}.group{hk}.dv", dv[0, :, hk], fdv[:, 0], "grad_ring")
     all_rows_relative(f"cfg3.{mode}.group{hk}.out", out[0, :, hs], fo)
-    all_rows_relative(f"cfg3.{mode}.group{hk}.dq", dq[0, :, hs], fdq)
+    all_rows_relative(f"cfg3.{mode}.group{hk}.dq", dq[0, :, hs], fdq, dq_allow)
     all_rows_relative(f"cfg3.{mode}.group{hk}.dk", dk[0, :, hk], fdk[:, 0])
     all_rows_relative(f"cfg3.{mode}.group{hk}.dv", dv[0, :, hk], fdv[:, 0])
 

@@ -41,15 +41,19 @@ def _row(name, i, h, got, ref):
 ROW_REL, ROW_FLOOR = 1e-2, 1e-4
 
 
-def all_rows_relative(name, got, ref):
+def all_rows_relative(name, got, ref, allowance=None):
     """EVERY row (last dim) of got against the exact fp64 ref, relative to the row's own norm — the criterion of _row,
-    vectorised: ||err_row|| <= ROW_REL ||ref_row|| + ROW_FLOOR sqrt(D)"""
+    vectorised: ||err_row|| <= ROW_REL ||ref_row|| + ROW_FLOOR sqrt(D) (+ allowance per row: dQ only, the effect of
+    delta being computed from the ROUNDED saved output — tests/_fullref.py: dq_delta_allowance; it is O(1) relative
+    for the first few rows of a sequence and vanishes for the others)"""
     import os
 
     got, ref = got.double().cpu(), ref.double().cpu()
     assert got.shape == ref.shape, f"{name}: {tuple(got.shape)} vs {tuple(ref.shape)}"
     en, rn = (got - ref).norm(dim=-1), ref.norm(dim=-1)
     lim = ROW_REL * rn + ROW_FLOOR * ref.shape[-1] ** 0.5
+    if allowance is not None:
+        lim = lim + allowance.double().cpu()
     worst = (en / lim).max().item()
     path = os.environ.get("RFA_TOL_LOG")
     if path:
@@ -136,7 +140,7 @@ def test_headline_full_tensor_one_kv_group(single_rank_group, hk):
     fo, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(qs[0].to(dev), ks[0].to(dev), vs[0].to(dev), dos[0].to(dev))
     assert (got["lse"].double() - fl.cpu()).abs().max().item() < 2e-5 + 2e-6 * fl.abs().max().item()
     all_rows_relative(f"headline.group{hk}.out", got["out"], fo)
-    all_rows_relative(f"headline.group{hk}.dq", got["dq"], fdq)
+    all_rows_relative(f"headline.group{hk}.dq", got["dq"], fdq, _fullref.attention_fwd_bwd_fp64.dq_delta_allowance)
     all_rows_relative(f"headline.group{hk}.dk", got["dk"], fdk[:, 0])
     all_rows_relative(f"headline.group{hk}.dv", got["dv"], fdv[:, 0])
 
@@ -210,6 +214,6 @@ def test_max_length_65536_single_gpu(single_rank_group):
     _, fl, fdq, fdk, fdv = _fullref.attention_fwd_bwd_fp64(q[0, j:, hs].to(dev), kv[0, :, 0, hk:hk + 1].to(dev),
                                                           kv[0, :, 1, hk:hk + 1].to(dev), do[0, j:, hs].to(dev))
     assert (lse[0, hs, j:] - fl.cpu()).abs().max().item() < 2e-5 + 2e-6 * fl.abs().max().item()
-    all_rows_relative("s65536.dq", dq[0, j:, hs], fdq)
+    all_rows_relative("s65536.dq", dq[0, j:, hs], fdq, _fullref.attention_fwd_bwd_fp64.dq_delta_allowance)
     all_rows_relative("s65536.dk", dkv[0, j:, 0, hk], fdk[j:, 0])
     all_rows_relative("s65536.dv", dkv[0, j:, 1, hk], fdv[j:, 0])

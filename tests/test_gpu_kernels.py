@@ -331,8 +331,10 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
     be.bwd_preprocess(dod, out, delta)
     lse_b = torch.where(torch.isinf(lse), torch.zeros_like(lse), lse)       # rows without keys: P = 0 either way
     res = {}
+    from ring_flash_attn import config
+
     for spill in (True, False):
-        os.environ["RFA_BWD_DS_SPILL"] = "1" if spill else "0"
+        config.set(bwd_ds_spill=spill)
         dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
         be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv)
         dqa = torch.full((B, Sq, H, 128), 3.0, dtype=torch.float32, device=dev)

@@ -180,7 +180,8 @@ def _dropout_fp64(q, k, v, do, causal, p, keep):
         i = torch.arange(Sq).view(-1, 1) + (Sk - Sq)
         s = s.masked_fill(torch.arange(Sk).view(1, -1) > i, float("-inf"))
     pr = torch.nan_to_num(torch.softmax(s, -1), nan=0.0)
-    out = torch.einsum("bhqk,bkhd->bqhd", torch.where(keep, pr / (1 - p), torch.zeros_like(pr)),
+    # kept probabilities are rescaled by 256 / round((1 - p) 256): the reciprocal of the rate the mask really keeps at
+    out = torch.einsum("bhqk,bkhd->bqhd", torch.where(keep, pr * (256.0 / R.drop_threshold(p)), torch.zeros_like(pr)),
                        vd.repeat_interleave(H // Hk, dim=2))
     out.backward(do.double())
     return out.detach(), qd.grad, kd.grad, vd.grad

@@ -58,8 +58,9 @@ def test_zigzag_under_activation_checkpointing_matches_golden(monkeypatch):
 def test_kept_kv_is_owned_by_the_autograd_graph():
     """the K/V gathered by the zigzag forward are SAVED TENSORS of its autograd node: present exactly when a backward
     can follow (not under torch.no_grad(), not for inputs without requires_grad), freed with the graph, not kept over
-    RFA_ZIGZAG_KV_KEEP_BYTES / with RFA_ZIGZAG_KV_KEEP=0 (the backward then gathers again, same gradients).  No
-    process-global state is involved (round-2 review)."""
+    config.kv_keep_bytes / with config.kv_keep = False / beyond the process-wide budget config.kv_keep_total_bytes of all
+    pending backwards (the backward then gathers again, same gradients).  The only process-global state is that byte
+    count."""
     import torch.multiprocessing as mp
     import _kv_cache_worker as KW
     from ring_flash_attn import zigzag_ring_flash_attn as Z, utils as U
@@ -68,7 +69,7 @@ def test_kept_kv_is_owned_by_the_autograd_graph():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(KW.run, args=(2, free_port(), ret), nprocs=2, join=True)
-    want = [6, True, None, None, 5, True, 5, True]
+    want = [6, True, None, None, 5, True, 5, True, 6, 5, True, True, 6, True]
     assert ret[0] == want and ret[1] == want, dict(ret)
 
 
@@ -393,7 +394,7 @@ def _llama3_groups_rank(rank, W, port, ret):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=W)
     import ring_flash_attn as R
-    from ring_flash_attn import backend
+    from ring_flash_attn import backend, config
     from oracle.oracle_backend import OracleBackend
 
     backend.set_backend(OracleBackend())
@@ -406,7 +407,7 @@ def _llama3_groups_rank(rank, W, port, ret):
     cq, ck, mq, mk, ks = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, rank, W)
     res = {}
     for budget in ("0", str(1 << 30)):          # 4 groups of one kv head (buffers reused twice) vs one fused group
-        os.environ["RFA_LLAMA3_GATHER_MAX_BYTES"] = budget
+        config.set(llama3_gather_max_bytes=int(budget))
         ql, kl, vl = (t[sl].clone().requires_grad_(True) for t in (q, k, v))
         out, lse, _ = R.llama3_flash_attn_varlen_func(ql, kl, vl, cq, ck, mq, mk, heads_k_stride=1, local_k_slice=ks,
                                                       causal=True, return_attn_probs=True)

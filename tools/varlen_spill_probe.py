@@ -17,6 +17,7 @@ for cu in pats:
     cut = torch.tensor(cu, device=dev, dtype=torch.int32); mx = max(b - a for a, b in zip(cu[:-1], cu[1:]))
     for sp in (("1", "0") if len(sys.argv) < 3 else (sys.argv[2],)):
         os.environ["RFA_BWD_DS_SPILL"] = sp
+        __import__("ring_flash_attn").config.reload()
         def step():
             q.grad = None; kv.grad = None
             R.zigzag_ring_flash_attn_varlen_kvpacked_func(q, kv, cut, mx, causal=True).backward(do)
