@@ -29,29 +29,74 @@ ALGO = {
 HANDOFF = {"dkdv_kernel+spill": DS, "dq_ds_kernel": DS}
 
 
-def main():
-    src, dst = sys.argv[1], sys.argv[2]
-    vals = {}
+KEEP = ("FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+        "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "EFFECTIVE_CLOCK_GHZ")
+
+
+def parse(src):
+    """{section ("hk8" | "hk32"): {kernel: {counter: per-dispatch average}}} — a line `== pass: <name>` opens a pass; pass
+    names ending in _hk32 belong to the MHA (--kv-heads 32) runs"""
+    vals, sec = {}, "hk8"
     for line in open(src):
-        m = re.match(r"\s*(\S+)\s+(FETCH_SIZE|WRITE_SIZE)\s+([0-9.]+)", line)
+        m = re.match(r"== pass: (\S+)", line)
+        if m:
+            sec = "hk32" if m.group(1).endswith("_hk32") else "hk8"
+            continue
+        m = re.match(r"\s*(\S+)\s+(" + "|".join(KEEP) + r")\s+([0-9.]+)", line)
         if not m:
             continue
         name = m.group(1)
         for key in ("dq_ds_kernel", "dkdv_kernel", "dq_kernel", "fwd_kernel"):
             if key in name:
                 spill = key == "dkdv_kernel" and "ELb1ELb1E" in name
-                vals.setdefault(key + ("+spill" if spill else ""), {})[m.group(2)] = float(m.group(3))
+                vals.setdefault(sec, {}).setdefault(key + ("+spill" if spill else ""), {})[m.group(2)] = float(m.group(3))
                 break
-    out = {"_source": f"{os.path.basename(src)} (profiles/collect_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                      "over python bench.py, headline shape Hk=8, per launch); FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024",
-           "library_build_id": sys.argv[3] if len(sys.argv) > 3 else None}
+    return vals
+
+
+def entries(vals, hk):
+    kb = S * hk * D * 2
+    algo = {
+        "fwd_kernel": QB + 2 * kb + QB + LSE,
+        "dq_kernel": 2 * QB + 2 * kb + 2 * LSE + QB,
+        "dkdv_kernel": 2 * QB + 2 * kb + 2 * LSE + 2 * kb,
+        "dkdv_kernel+spill": 2 * QB + 2 * kb + 2 * LSE + 2 * kb,
+        "dq_ds_kernel": kb + QB,
+    }
+    out = {}
     for key, v in vals.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            out[key] = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
-                        "hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024),
-                        "algorithmic_bytes": ALGO.get(key), "handoff_bytes": HANDOFF.get(key, 0)}
+            e = {"fetch_kib": v["FETCH_SIZE"], "write_kib": v["WRITE_SIZE"],
+                 "hbm_bytes_per_launch": int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024),
+                 "algorithmic_bytes": algo.get(key), "handoff_bytes": HANDOFF.get(key, 0)}
+            e["traffic_over_algorithmic"] = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"] if e["algorithmic_bytes"] else None
+            # issue-side counters of the same build (per dispatch, averaged over the counter's instances; SQ_* in
+            # quad-cycles) and the clock the profiled pass ran at: a cycle saving must show here, not only in wall time
+            for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
+                      "GRBM_GUI_ACTIVE"):
+                if c in v:
+                    e[c.lower()] = v[c]
+            if "EFFECTIVE_CLOCK_GHZ" in v:
+                e["effective_clock_ghz_profiled"] = v["EFFECTIVE_CLOCK_GHZ"]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "SQ_WAVE_CYCLES" in v:
+                e["mfma_pipe_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (2.0 * v["SQ_WAVE_CYCLES"])
+            out[key] = e
     if "dkdv_kernel+spill" in out:
         out["dkdv_kernel"] = out["dkdv_kernel+spill"]       # the instance the product path launches
+    return out
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    parsed = parse(src)
+    vals = parsed.get("hk8", {})
+    out = {"_source": f"{os.path.basename(src)} (profiles/collect_pmc.sh: separate rocprofv3 --pmc passes over python bench.py, "
+                      "headline shape, per launch); hbm bytes = FETCH_SIZE KiB x 1024 x 2 + WRITE_SIZE KiB x 1024; the top-level "
+                      "entries are the Hk = 8 (GQA) runs, `hk32` the --kv-heads 32 (MHA) runs",
+           "library_build_id": sys.argv[3] if len(sys.argv) > 3 else None}
+    out.update(entries(vals, HK))
+    if "hk32" in parsed:
+        out["hk32"] = entries(parsed["hk32"], 32)
     json.dump(out, open(dst, "w"), indent=1)
 
 

@@ -27,9 +27,19 @@ def main():
              f"join {kd} d on e.event_id=d.event_id join {ks} s on d.kernel_id=s.id group by s.kernel_name, p.name "
              f"order by s.kernel_name, p.name")
         print("\nper-dispatch counter averages")
+        gui = {}
         for r in c.execute(q):
             if "rfa" in r[0]:
                 print(f"{r[0][:60]:60s} {r[1]:36s} {r[2]:18.1f} (n={r[3]})")
+                if r[1] == "GRBM_GUI_ACTIVE":
+                    gui[r[0]] = r[2]
+        # effective shader clock of a kernel IN THIS (profiled) PASS = GRBM_GUI_ACTIVE (cycles an XCD was busy with the
+        # dispatch, averaged over the counter's instances) / the dispatch's duration in the same database
+        # (MI355X_MICROARCH.md, "DVFS give-back": the chip clocks to its power budget; profiled passes run a few % lower)
+        dur = {r[0]: r[2] for r in rows}
+        for name, cyc in gui.items():
+            if dur.get(name):
+                print(f"{name[:60]:60s} {'EFFECTIVE_CLOCK_GHZ':36s} {cyc / dur[name]:18.3f} (GRBM_GUI_ACTIVE / avg duration {dur[name] / 1e3:.1f} us)")
 
 
 if __name__ == "__main__":

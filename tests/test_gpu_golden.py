@@ -36,3 +36,25 @@ def test_zigzag_varlen_gather_exchange_hip_matches_golden(W, monkeypatch):
     assert names
     errs = RW.run_world(W, names, use_hip=True, port=free_port())
     assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_schedules_under_torch_compile_at_world_size_gt_1_on_the_hip_kernels(W, monkeypatch):
+    """The reference runs every test a second time with the function under torch.compile at the full world size
+    (/root/reference/test/test.sh:23-25, test/test_zigzag_ring_flash_attn_func.py:105-108).  GPU twin of
+    tests/test_schedules_cpu.py::test_schedules_under_torch_compile_at_world_size_gt_1: W processes share the GPU, every
+    public function is called through a torch.compile'd caller (traced tensor work on both sides of the call; the
+    multi-rank schedule itself is a deliberate graph break) on the HIP kernels, and must reproduce the golden vectors of
+    the unmodified reference — both exchange forms of the zigzag path, and the other schedules."""
+    import _ring_worker as RW
+    import make_golden as MG
+    from conftest import free_port
+
+    monkeypatch.setenv("RFA_TEST_COMPILE", "1")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W]        # (incl. the head-dim-128 multi-tile cases: the LDS-DMA instances)
+    assert names
+    for mode in ("gather", "ring"):
+        monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
+        sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
+        errs = RW.run_world(W, sel, use_hip=True, port=free_port())
+        assert not errs, "\n".join(errs)
