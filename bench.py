@@ -140,7 +140,7 @@ def committed_traffic(kernel, hk):
     for n in sorted(os.listdir(pdir)):
         if n.endswith("_traffic.json"):
             best = n
-    if best is None or hk != 8:
+    if best is None or hk not in (8, 32):
         return None, "no PMC traffic pass committed for this configuration"
     tr = json.load(open(os.path.join(pdir, best)))
     have = tr.get("library_build_id")
@@ -148,9 +148,10 @@ def committed_traffic(kernel, hk):
         sys.stderr.write(f"bench.py: profiles/{best} was collected on another build of librfa_hip.so "
                          f"({have} vs {library_digest()}): roofline.traffic withheld — re-run profiles/collect_pmc.sh\n")
         return None, f"profiles/{best} is stale for this librfa_hip.so (re-run profiles/collect_pmc.sh)"
-    if kernel not in tr:
-        return None, f"profiles/{best} has no entry for {kernel}"
-    return tr[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
+    sect = tr if hk == 8 else tr.get("hk32", {})         # (top level: the Hk = 8 runs; "hk32": --kv-heads 32)
+    if kernel not in sect:
+        return None, f"profiles/{best} has no entry for {kernel} at kv_heads {hk}"
+    return sect[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
 
 
 class _Hip:
@@ -931,6 +932,11 @@ def main():
                 "avg_launch_ms": t_in[dom],
                 "timed": "in-step" if in_step_line else "isolated launches of the local block",
                 "clock_avg_mhz": (result["clock"] or {}).get("avg_mhz"),
+                # issue-side counters and the clock of the PROFILED passes of the same build (profiles/collect_pmc.sh):
+                # wave cycles / busy fractions say whether a change saved cycles or only moved the clock
+                "profiled": ({k_: entry[k_] for k_ in ("effective_clock_ghz_profiled", "mfma_pipe_busy", "sq_wave_cycles",
+                                                       "sq_active_inst_any", "sq_wait_any", "sq_wait_inst_any") if k_ in entry}
+                             if entry else None),
             }
             result["kernels_ms"] = {k2: round(v2, 4) for k2, v2 in t_in.items()}
             result["kernels_ms_isolated"] = {k2: round(v2, 4) for k2, v2 in iso.items()}

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RFA_ABI_VERSION 4
+#define RFA_ABI_VERSION 5
 
 typedef enum {
   RFA_OK = 0,
@@ -209,6 +209,14 @@ typedef struct {
   uint64_t dropout_seed;
   int64_t q_pos_offset, k_pos_offset;
   int32_t head_offset;
+  /* ABI 5: size of the buffer `ds_scratch` points to.  0 = at least rfa_bwd_ds_scratch_bytes().  A SMALLER buffer does
+   * not switch the 5-GEMM form off: the call then runs it in HEAD-GROUP CHUNKS that reuse the one buffer — chunks of
+   * whole K/V heads (with their query heads) or, where even one K/V head's query heads do not fit, fractions of ONE
+   * K/V head's query heads, whose dK/dV shares are accumulated in the fp32 partials — each chunk one dK/dV launch and
+   * one dQ launch, in stream order.  Peak scratch is then independent of the head count and the long-context cases
+   * (S = 32768, 32 heads: 34 GB of dS) keep the 5-GEMM form (rfa_bwd_ds_chunks() reports the chunking; head dim 128
+   * only; a buffer below one query head's share, rfa_bwd_ds_scratch_min_bytes(), falls back to the 7-GEMM form). */
+  int64_t ds_scratch_bytes;
 } rfa_bwd_args;
 
 enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };
@@ -261,6 +269,12 @@ int rfa_bwd_plan(const rfa_bwd_args *args, int32_t *form, int32_t *nsplit, int32
 /* bytes of ds_scratch the call would use (B*H*ceil(Sq/32)*ceil(Sk/32)*2048; packed input: B sequences, Sq / Sk =
  * max_seqlen_q / _k; with q_half / k_half: ceil(S/2) instead of S), or 0 if it is not eligible */
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args *args);
+/* the smallest ds_scratch with which the call still runs the 5-GEMM form (one query head's dS; 0: not eligible) */
+int64_t rfa_bwd_ds_scratch_min_bytes(const rfa_bwd_args *args);
+/* the chunking of the call's dS hand-off for its (ds_scratch, ds_scratch_bytes): *nchunks = launches pairs (0: the
+ * call runs the 7-GEMM form, 1: one pair over all heads), *kv_heads / *q_heads = K/V heads and query heads PER K/V HEAD
+ * of one chunk, *chunk_bytes = scratch bytes one chunk uses.  Pure function of the arguments. */
+int rfa_bwd_ds_chunks(const rfa_bwd_args *args, int32_t *nchunks, int32_t *kv_heads, int32_t *q_heads, int64_t *chunk_bytes);
 int rfa_bwd(const rfa_bwd_args *args, void *stream);
 int rfa_merge(const rfa_merge_args *args, void *stream);
 

@@ -172,7 +172,10 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 // launch needs that many for its heavy-first order to balance), each with at least 8 tiles.  Launches that stay
 // small even so run the 128-key form (twice the workgroups).
 struct DkdvPlan { int wide, nsplit; };
-static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
+struct DsChunks { int nchunks, hc, gc; int64_t chunk_bytes; };     // hc K/V heads x gc query heads per K/V head per chunk
+static DsChunks bwd_ds_chunking(const rfa_bwd_args* a);
+// hk_launch: K/V heads of ONE dK/dV launch (= Hk, or the K/V heads of a chunk of a chunked dS hand-off)
+static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
   DkdvPlan pl{0, 1};
   if (a->D > kHeadDim) {
     // rfa_bigd.hip: 128-key workgroups that occupy a CU each (one wave per SIMD).  A causal launch is as long as its
@@ -185,7 +188,7 @@ static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
       kb = eff < kb ? eff : kb;
     }
     int ns = 1;
-    while (ns < 4 && kb * a->Hk * ns < 448 && sq_ / (ns + 1) >= 256) ++ns;
+    while (ns < 4 && kb * hk_launch * ns < 448 && sq_ / (ns + 1) >= 256) ++ns;
     if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
     pl.nsplit = ns;
     return pl;
@@ -200,7 +203,7 @@ static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
     const int64_t eff = (a->total_k + 255) / 256 + a->B;
     kblocks = eff < kblocks ? eff : kblocks;
   }
-  const int64_t wgs = kblocks * a->Hk;
+  const int64_t wgs = kblocks * hk_launch;
   int ns = 1;
   while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 512) ++ns;
   const bool forced = a->dkdv_form == RFA_DKDV_256;
@@ -210,9 +213,14 @@ static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   pl.nsplit = ns;
   return pl;
 }
+static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
+  const DsChunks ch = bwd_ds_chunking(a);
+  return bwd_dkdv_plan_for(a, ch.nchunks > 1 ? ch.hc : a->Hk);
+}
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
   if (!bwd_single_phase(a)) return true;
   if (bwd_dkdv_plan(a).nsplit > 1) return true;
+  if (bwd_ds_chunking(a).gc < a->H / a->Hk) return true;      // query-head fractions of a K/V head accumulate in fp32 partials
   return a->dk_acc != nullptr && !bwd_kv_direct(a);
 }
 
@@ -232,10 +240,62 @@ static int bwd_ds_c(const rfa_bwd_args* a) {
   return c > nkb ? nkb : c;
 }
 
+// dS bytes of ONE query head (all batches / packed sequences)
+static int64_t bwd_ds_head_bytes(const rfa_bwd_args* a) {
+  const int64_t per_head = ds_row_off(ds_blocks(a->Sq, a->q_half), ds_blocks(a->Sk, a->k_half), bwd_ds_c(a), 1);
+  return (int64_t)a->B * per_head * kDsBlockBytes;
+}
+
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_spill_eligible(a)) return 0;
-  const int64_t per_head = ds_row_off(ds_blocks(a->Sq, a->q_half), ds_blocks(a->Sk, a->k_half), bwd_ds_c(a), 1);
-  return (int64_t)a->B * a->H * per_head * kDsBlockBytes;
+  return (int64_t)a->H * bwd_ds_head_bytes(a);
+}
+
+int64_t rfa_bwd_ds_scratch_min_bytes(const rfa_bwd_args* a) {
+  if (!a || !bwd_spill_eligible(a)) return 0;
+  // head dim 256 (rfa_bigd.hip) has no chunked form; two-phase calls (COMPUTE / REDUCE) chunk by whole K/V heads only
+  if (a->D != kHeadDim) return rfa_bwd_ds_scratch_bytes(a);
+  const int G = a->H / a->Hk;
+  return (bwd_single_phase(a) ? 1 : G) * bwd_ds_head_bytes(a);
+}
+
+// How the dS hand-off of a call is cut to fit the scratch it was given: all heads at once when they fit; else chunks
+// of hc whole K/V heads (hc the largest divisor of Hk whose query heads fit); else — not even one K/V head's G query
+// heads fit — chunks of gc query heads of ONE K/V head (gc the largest divisor of G that fits), whose dK/dV shares are
+// accumulated in the fp32 partials of the workspace (kv_accum).  nchunks = 0: the 7-GEMM form.
+static DsChunks bwd_ds_chunking(const rfa_bwd_args* a) {
+  DsChunks none{0, a->Hk, a->H / a->Hk, 0};
+  if (a->ds_scratch == nullptr || !bwd_spill_eligible(a)) return none;
+  const int G = a->H / a->Hk;
+  const int64_t per = bwd_ds_head_bytes(a);
+  const int64_t full = per * a->H;
+  const int64_t avail = a->ds_scratch_bytes > 0 ? a->ds_scratch_bytes : full;
+  if (per <= 0) return none;
+  if (avail >= full) return DsChunks{1, a->Hk, G, full};
+  if (a->D != kHeadDim) return none;
+  const int64_t fit = avail / per;                       // query heads whose dS fit
+  if (fit >= G) {
+    int hc = 1;
+    for (int d = 1; d <= a->Hk; ++d)
+      if (a->Hk % d == 0 && (int64_t)d * G <= fit) hc = d;
+    return DsChunks{a->Hk / hc, hc, G, per * hc * G};
+  }
+  if (fit < 1 || !bwd_single_phase(a)) return none;
+  int gc = 1;
+  for (int d = 1; d <= G; ++d)
+    if (G % d == 0 && d <= fit) gc = d;
+  return DsChunks{a->Hk * (G / gc), 1, gc, per * gc};
+}
+
+int rfa_bwd_ds_chunks(const rfa_bwd_args* a, int32_t* nchunks, int32_t* kv_heads, int32_t* q_heads, int64_t* chunk_bytes) {
+  if (!a) return RFA_ERR_NULL;
+  if (int rc = check_common(a->dtype, a->H, a->Hk, a->D, a->B)) return rc;
+  const DsChunks ch = bwd_ds_chunking(a);
+  if (nchunks) *nchunks = ch.nchunks;
+  if (kv_heads) *kv_heads = ch.hc;
+  if (q_heads) *q_heads = ch.gc;
+  if (chunk_bytes) *chunk_bytes = ch.chunk_bytes;
+  return RFA_OK;
 }
 
 int rfa_bwd_plan(const rfa_bwd_args* a, int32_t* form, int32_t* nsplit, int32_t* five_gemm) {
@@ -243,7 +303,7 @@ int rfa_bwd_plan(const rfa_bwd_args* a, int32_t* form, int32_t* nsplit, int32_t*
   const DkdvPlan pl = bwd_dkdv_plan(a);
   if (form) *form = pl.wide ? RFA_DKDV_256 : RFA_DKDV_128;
   if (nsplit) *nsplit = pl.nsplit;
-  if (five_gemm) *five_gemm = (a->ds_scratch != nullptr && bwd_spill_eligible(a)) ? 1 : 0;
+  if (five_gemm) *five_gemm = bwd_ds_chunking(a).nchunks > 0 ? 1 : 0;
   return RFA_OK;
 }
 
@@ -251,7 +311,8 @@ int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
   // unsplit: one io-dtype partial per element; split launches: nsplit fp32 partials
   const int ns = bwd_dkdv_plan(a).nsplit;
-  return 2 * a->total_k * (int64_t)a->Hk * a->D * (ns > 1 ? 4 * ns : 2);
+  const bool f32 = ns > 1 || bwd_ds_chunking(a).gc < a->H / a->Hk;
+  return 2 * a->total_k * (int64_t)a->Hk * a->D * (f32 ? 4 * ns : 2);
 }
 
 int rfa_bwd(const rfa_bwd_args* a, void* stream) {
@@ -301,22 +362,27 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
   p.nqblk = (eff_len(a->Sq, a->q_half) + bwd_dq_rows_per_block() - 1) / bwd_dq_rows_per_block();
+  const DsChunks chunks = bwd_ds_chunking(a);
+  const int Gfull = a->H / a->Hk;
+  const bool frac = chunks.nchunks > 0 && chunks.gc < Gfull;       // query-head fractions of a K/V head per launch
   const DkdvPlan plan = bwd_dkdv_plan(a);
   p.wide = plan.wide; p.nsplit = plan.nsplit;
   p.nkblk = (eff_len(a->Sk, a->k_half) + bwd_dkdv_keys_per_block(plan.wide) - 1) / bwd_dkdv_keys_per_block(plan.wide);
 
   Strides ws_st{};
-  if (bwd_kv_direct(a) && plan.nsplit == 1) {
+  const bool part_f32 = plan.nsplit > 1 || frac;
+  if (bwd_kv_direct(a) && !part_f32) {
     p.dk = a->dk_acc; p.dv = a->dv_acc;
     p.dk_st = cv(a->dk_acc_st); p.dv_st = cv(a->dv_acc_st);
     p.kv_f32 = 1;
   } else if (ws) {
     // partials: (rows, Hk, nsplit, D) contiguous; dense rows = b*Sk + row (own batch stride).  The kernel addresses
     // K/V head hk of split s at element (hk * nsplit + s) * D of a row, reduce_kernel reads the nsplit entries of
-    // a K/V head as its "group" (G = nsplit, head stride D).  Split launches keep fp32 partials (summed, then
-    // rounded once — the rounding an unsplit launch does); unsplit ones the io dtype.
+    // a K/V head as its "group" (G = nsplit, head stride D).  Split launches — and launches that cover a fraction of
+    // a K/V head's query heads (chunked dS hand-off: the later fractions ADD to the partial) — keep fp32 partials
+    // (summed, then rounded once: the rounding an unsplit launch does); the others the io dtype.
     const int64_t ns = plan.nsplit;
-    const int64_t esz = ns > 1 ? 4 : 2;
+    const int64_t esz = part_f32 ? 4 : 2;
     ws_st.head = a->D;
     ws_st.row = (int64_t)a->Hk * ns * a->D;
     ws_st.batch = a->cu_seqlens_k ? 0 : (int64_t)a->Sk * a->Hk * ns * a->D;
@@ -325,7 +391,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     p.dk_st = ws_st; p.dv_st = ws_st;
     p.dk_st.head = p.dv_st.head = ns * a->D;
     p.kv_split_stride = a->D;
-    p.kv_f32 = p.kv_part_f32 = ns > 1 ? 1 : 0;
+    p.kv_f32 = p.kv_part_f32 = part_f32 ? 1 : 0;
   } else {
     p.dk = a->dk; p.dv = a->dv;
     p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
@@ -338,18 +404,42 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   const bool do_reduce = bwd_single_phase(a) || (a->phases & RFA_BWD_REDUCE);
   const int kv_init = (a->acc_init || (a->phases & RFA_BWD_KV_OVERWRITE)) ? 1 : 0;
   if (do_compute) {
-    const bool spill = a->ds_scratch != nullptr && bwd_spill_eligible(a);
-    if (spill) {
-      // 5-GEMM form: dK/dV kernel first (it stores dS), then dQ streams dS back
+    if (chunks.nchunks > 0) {
+      // 5-GEMM form: dK/dV kernel first (it stores dS), then dQ streams dS back — once over all heads, or (a scratch
+      // smaller than the whole hand-off) chunk by chunk over head groups that reuse the one scratch in stream order
       if (!aligned16(a->ds_scratch)) return RFA_ERR_ALIGN;
+      if (chunks.nchunks > 1 && (a->phases & (RFA_BWD_SKIP_DKDV | RFA_BWD_SKIP_DQ))) return RFA_ERR_ARGS;
       p.ds = a->ds_scratch;
       p.ds_c = bwd_ds_c(a);
       p.ds_tri = p.ds_c < ds_blocks(a->Sk, a->k_half) ? 1 : 0;
-      if (!(a->phases & RFA_BWD_SKIP_DKDV))
-        if (int rc2 = launch_bwd_dkdv(p, a->dtype, st)) return launch_status(rc2);
-      mark(1);
-      if (!(a->phases & RFA_BWD_SKIP_DQ))
-        if (int rc2 = launch_bwd_dq_from_ds(p, a->dtype, st)) return launch_status(rc2);
+      const int nfrac = Gfull / chunks.gc;
+      const int64_t kv_esz = p.kv_f32 ? 4 : 2;
+      for (int c = 0; c < chunks.nchunks; ++c) {
+        BwdParams pc = p;
+        if (chunks.nchunks > 1) {
+          const int hk0 = frac ? c / nfrac : c * chunks.hc;      // first K/V head of the chunk
+          const int f = frac ? c % nfrac : 0;                    // which fraction of that K/V head's query heads
+          const int64_t qh0 = (int64_t)hk0 * Gfull + (int64_t)f * chunks.gc;   // first query head
+          pc.Hk = chunks.hc;
+          pc.H = chunks.hc * chunks.gc;
+          pc.q = (const char*)p.q + qh0 * p.q_st.head * 2;
+          pc.dout = (const char*)p.dout + qh0 * p.dout_st.head * 2;
+          pc.lse = p.lse + qh0 * p.lse_head;
+          pc.delta = p.delta + qh0 * p.delta_head;
+          if (p.dq_acc) pc.dq_acc = p.dq_acc + qh0 * p.dq_acc_st.head;
+          else pc.dq = (char*)p.dq + qh0 * p.dq_st.head * 2;
+          pc.k = (const char*)p.k + (int64_t)hk0 * p.k_st.head * 2;
+          pc.v = (const char*)p.v + (int64_t)hk0 * p.v_st.head * 2;
+          pc.dk = (char*)p.dk + (int64_t)hk0 * p.dk_st.head * kv_esz;
+          pc.dv = (char*)p.dv + (int64_t)hk0 * p.dv_st.head * kv_esz;
+          pc.kv_accum = f > 0 ? 1 : 0;
+        }
+        if (!(a->phases & RFA_BWD_SKIP_DKDV))
+          if (int rc2 = launch_bwd_dkdv(pc, a->dtype, st)) return launch_status(rc2);
+        if (c == 0) mark(1);
+        if (!(a->phases & RFA_BWD_SKIP_DQ))
+          if (int rc2 = launch_bwd_dq_from_ds(pc, a->dtype, st)) return launch_status(rc2);
+      }
       mark(2);
     } else {
       if (!(a->phases & RFA_BWD_SKIP_DQ))
@@ -368,7 +458,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     ReduceParams r{};
     r.src = p.dk; r.src2 = p.dv;
     r.src_st = ws_st;
-    r.src_f32 = plan.nsplit > 1 ? 1 : 0;
+    r.src_f32 = part_f32 ? 1 : 0;
     r.cu_k = a->cu_seqlens_k;
     r.B = a->B; r.Hk = a->Hk; r.G = plan.nsplit; r.D = a->D; r.Sk = a->Sk;   // query-head groups are already summed
     r.k_half = a->k_half; r.acc_init = kv_init;

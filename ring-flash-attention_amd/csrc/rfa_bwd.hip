@@ -901,6 +901,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
             f32x4 x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+            if (p.kv_accum) {                      // (a later query-head fraction of a chunked launch sequence)
+              const f32x4 old = *(f32x4*)(ob + d0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[e] += old[e];
+            }
             *(f32x4*)(ob + d0) = x;
           }
         }

@@ -87,6 +87,7 @@ struct BwdParams {
   int wide, nsplit;
   int64_t kv_split_stride;
   int kv_part_f32;     // dk / dv point to fp32 PARTIALS in the workspace (split launches): fp32 stores, strides in fp32 elements
+  int kv_accum;        // fp32 stores ADD to what the partial holds (later query-head fractions of a chunked dS hand-off)
   // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
   // the offsets that turn local (head, query position, key position) into global ones
   unsigned drop_keep;

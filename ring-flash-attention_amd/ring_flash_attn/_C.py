@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RFA_LIB_PATH: A/B tooling only (tools/ab_variants.py builds tuning variants of the same library)
 LIB_PATH = os.environ.get("RFA_LIB_PATH") or os.path.join(_HERE, "librfa_hip.so")
 
-RFA_ABI_VERSION = 4
+RFA_ABI_VERSION = 5
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
@@ -87,6 +87,7 @@ class BwdArgs(C.Structure):
         ("prof_events", C.POINTER(C.c_void_p)),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
+        ("ds_scratch_bytes", C.c_int64),
     ]
 
 
@@ -122,6 +123,9 @@ SYMBOLS = {
     "rfa_bwd_preprocess": (C.c_int, [C.POINTER(BwdPreArgs), C.c_void_p]),
     "rfa_bwd_workspace_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
     "rfa_bwd_ds_scratch_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
+    "rfa_bwd_ds_scratch_min_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
+    "rfa_bwd_ds_chunks": (C.c_int, [C.POINTER(BwdArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_int64)]),
     "rfa_bwd_plan": (C.c_int, [C.POINTER(BwdArgs), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rfa_bwd": (C.c_int, [C.POINTER(BwdArgs), C.c_void_p]),
     "rfa_merge": (C.c_int, [C.POINTER(MergeArgs), C.c_void_p]),

@@ -58,6 +58,7 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _C.load()
+        self._ds_pool = {}            # (device index, stream handle) -> the ONE reusable dS scratch of that stream
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -192,21 +193,25 @@ class HipBackend:
         if prof_events is not None:       # measurement (bench.py): a ctypes array of 4 hipEvent_t, see include/rfa.h
             a.prof_events = prof_events
         reduce_only = bool(phases & _C.BWD_REDUCE) and not (phases & _C.BWD_COMPUTE)
-        # dK/dV launch plan: part of the call (ABI 4).  The tuning / test overrides RFA_DKDV_WIDE, RFA_DKDV_NSPLIT are
-        # read HERE, once per backward: a REDUCE call reuses the plan its COMPUTE call ran with (it travels with the
-        # `partials` token), so the two phases cannot disagree whatever happens to the environment in between.
+        # dK/dV launch plan: part of the call (ABI 4).  The tuning / test overrides (config.dkdv_wide, config.dkdv_nsplit)
+        # are applied HERE, once per backward; a REDUCE call is given the plan its COMPUTE call RESOLVED (it travels with
+        # the `partials` token), so the two phases cannot disagree whatever the configuration, or the chunking of the
+        # dS hand-off, does in between.
         if reduce_only and partials is not None and hasattr(partials, "_rfa_plan"):
             a.dkdv_form, a.dkdv_nsplit = partials._rfa_plan
         else:
             a.dkdv_form, a.dkdv_nsplit = _plan_overrides()
-        # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel spills dS and dQ streams it back instead of
-        # recomputing S and dP, when the call is eligible (D == 128 or 256, whole sequences, dense or packed) and the scratch
-        # fits (bwd_ds_scratch below); RFA_BWD_DS_SPILL=0 keeps the 7-GEMM form.  Callers that split one backward
-        # over several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
+        # 5-GEMM backward (csrc/rfa_dqs.hip): the dK/dV kernel hands dS to the dQ kernel through a scratch instead of dQ
+        # recomputing S and dP, when the call is eligible (D == 128 or 256, whole sequences, dense or packed).  The
+        # scratch is ONE reusable buffer per device and stream (bwd_ds_scratch below), at most config.ds_spill_max_bytes
+        # large: a hand-off that does not fit runs in head-group chunks over it (include/rfa.h: ds_scratch_bytes).
+        # config.bwd_ds_spill = False (RFA_BWD_DS_SPILL=0) keeps the 7-GEMM form.  Callers that split one backward over
+        # several calls (measurement: BWD_SKIP_DQ / BWD_SKIP_DKDV) pass the same `ds_scratch` to both.
         if ds_scratch is None and not reduce_only and _spill_enabled():
             ds_scratch = self.bwd_ds_scratch(a, q.device)
         if ds_scratch is not None and not reduce_only:
             a.ds_scratch = ds_scratch.data_ptr()
+            a.ds_scratch_bytes = ds_scratch.numel() * ds_scratch.element_size()
         nbytes = self.lib.rfa_bwd_workspace_bytes(C.byref(a))
         ws = None
         if reduce_only:
@@ -217,7 +222,8 @@ class HipBackend:
             ws = partials
         elif nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-            ws._rfa_plan = (a.dkdv_form, a.dkdv_nsplit)
+            form, ns, _ = self.bwd_plan(a)           # the RESOLVED plan (with this call's scratch): what a REDUCE call must repeat
+            ws._rfa_plan = (form, ns if form == _C.DKDV_256 or a.D > 128 else 0)
         if ws is not None:
             a.workspace = ws.data_ptr()
         _C.check(self.lib.rfa_bwd(C.byref(a), _stream(q)), "rfa_bwd")
@@ -229,33 +235,64 @@ class HipBackend:
         _C.check(self.lib.rfa_bwd_plan(C.byref(a), C.byref(form), C.byref(ns), C.byref(five)), "rfa_bwd_plan")
         return form.value, ns.value, five.value
 
+    def bwd_ds_chunks(self, a):
+        """(nchunks, kv_heads, q_heads_per_kv_head, chunk_bytes) of the dS hand-off of the call described by `a`
+        (nchunks 0: the 7-GEMM form)"""
+        n, hc, gc, cb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        _C.check(self.lib.rfa_bwd_ds_chunks(C.byref(a), C.byref(n), C.byref(hc), C.byref(gc), C.byref(cb)), "rfa_bwd_ds_chunks")
+        return n.value, hc.value, gc.value, cb.value
+
     def bwd_ds_scratch(self, a, device):
-        """Scratch tensor for the dS spill of the call described by `a` (a filled BwdArgs), or None: the call then
-        runs the 7-GEMM form.  The scratch is transient (one backward) but large — B*H*S^2 bytes for a dense causal
-        call, 2.2 GB at the headline shape, 8.6 GB at S = 16384 — so it is only taken when it stays below
-        RFA_DS_SPILL_MAX_BYTES (default 16 GiB) AND below RFA_DS_SPILL_MAX_FRAC (default 0.5) of the memory that is
-        free right now (device free + torch's cached-but-unused pool), and an allocation failure falls back to the
-        7-GEMM form instead of failing a backward that would have fitted without the spill.  Both refusals are
-        logged once per process."""
-        sbytes = self.lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
-        if sbytes <= 0:
+        """The dS scratch for the call described by `a` (a filled BwdArgs), or None: the call then runs the 7-GEMM form.
+
+        ONE buffer per (device, stream), kept and reused by every backward on that stream (kernels of one stream run in
+        order, so the next backward's dK/dV kernel cannot start before this one's dQ kernel has read the blocks) —
+        no 2 GB allocation per backward, and peak memory independent of the head count and the sequence length: the
+        buffer is at most config.ds_spill_max_bytes (default 2.5 GiB: the headline's 2.0 GiB hand-off in one piece) and,
+        when it is first taken or has to grow, at most config.ds_spill_max_frac (0.5) of the memory free at that moment;
+        a hand-off that does not fit runs in head-group chunks over it (include/rfa.h: ds_scratch_bytes; long contexts
+        keep the 5-GEMM form).  A hand-off whose smallest chunk does not fit, or an allocation failure, falls back to
+        the 7-GEMM form instead of failing a backward that would have fitted without it (logged once).
+        `release_scratch()` returns the buffers."""
+        full = self.lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
+        if full <= 0:
             return None
-        limit = _spill_limit()
-        if _SPILL_CHECK_ABOVE < sbytes <= limit and device.type == "cuda":
-            # (small requests skip the query: it costs host time on every backward)
+        least = self.lib.rfa_bwd_ds_scratch_min_bytes(C.byref(a))
+        want = min(full, max(_spill_limit(), 0))
+        key = (device.index if device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else ("cpu", 0)
+        buf = self._ds_pool.get(key)
+        if buf is not None and buf.numel() >= min(want, full):
+            return buf                                      # (the steady state: no query, no allocation)
+        if want < least:
+            _log_once("spill-limit", f"ring_flash_attn: the dS hand-off needs at least {least / 2**30:.2f} GiB per chunk "
+                                     f"(limit {want / 2**30:.2f} GiB): this backward runs the 7-GEMM form")
+            return None
+        if device.type == "cuda" and want > _SPILL_CHECK_ABOVE:
             free, _ = torch.cuda.mem_get_info(device)
             cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-            limit = min(limit, int(_spill_frac() * (free + cached)))
-        if sbytes > limit:
-            _log_once("spill-limit", f"ring_flash_attn: dS spill of {sbytes / 2**30:.2f} GiB refused (limit "
-                                     f"{limit / 2**30:.2f} GiB): this backward runs the 7-GEMM form")
-            return None
-        try:
-            return torch.empty(sbytes, dtype=torch.uint8, device=device)
-        except torch.OutOfMemoryError:
-            _log_once("spill-oom", f"ring_flash_attn: dS spill of {sbytes / 2**30:.2f} GiB could not be allocated: "
+            have = buf.numel() if buf is not None else 0
+            cap = int(_spill_frac() * (free + cached + have))
+            if cap < want:
+                want = cap
+        if want < least:
+            _log_once("spill-mem", f"ring_flash_attn: not enough free memory for a dS hand-off chunk ({least / 2**30:.2f} GiB): "
                                    "this backward runs the 7-GEMM form")
             return None
+        self._ds_pool.pop(key, None)
+        buf = None
+        try:
+            buf = torch.empty(want, dtype=torch.uint8, device=device)
+        except torch.OutOfMemoryError:
+            _log_once("spill-oom", f"ring_flash_attn: a dS hand-off scratch of {want / 2**30:.2f} GiB could not be allocated: "
+                                   "this backward runs the 7-GEMM form")
+            return None
+        self._ds_pool[key] = buf
+        return buf
+
+    def release_scratch(self):
+        """drop the reusable dS scratch buffers (they are re-made on demand)"""
+        self._ds_pool.clear()
 
     # ------------------------------------------------------------------ side kernels
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):

@@ -282,6 +282,38 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     monkeypatch.delenv("RFA_DKDV_WIDE")
     monkeypatch.delenv("RFA_DKDV_NSPLIT")
     assert BK._plan_overrides() == (_C.DKDV_AUTO, 0)
+    # ---- ABI 5: the dS hand-off runs in head-group chunks over a scratch smaller than the whole hand-off
+    def chunks(a, scratch_bytes):
+        a.ds_scratch, a.ds_scratch_bytes = 16, scratch_bytes
+        n, hc, gc, cb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        assert lib.rfa_bwd_ds_chunks(C.byref(a), C.byref(n), C.byref(hc), C.byref(gc), C.byref(cb)) == 0
+        return n.value, hc.value, gc.value, cb.value
+
+    per = lambda S: (S // 32) * (S // 32 + 1) // 2 * 2048       # one query head of a dense causal call
+    GiB = 1 << 30
+    # the headline fits 2.5 GiB in one piece (2.0 GiB); 0 = "at least the whole hand-off"
+    assert chunks(args(1, 8192, 8192, 32, 8, causal=True), 5 * GiB // 2) == (1, 8, 4, 32 * per(8192))
+    assert chunks(args(1, 8192, 8192, 32, 8, causal=True), 0) == (1, 8, 4, 32 * per(8192))
+    # S = 16384: 8.6 GB of dS -> 4 chunks of 2 K/V heads (8 query heads, 2.15 GB); the launch plan is that of a 2-head launch
+    a16 = args(1, 16384, 16384, 32, 8, causal=True)
+    assert ds(a16) == 32 * per(16384) and chunks(a16, 5 * GiB // 2) == (4, 2, 4, 8 * per(16384))
+    assert plan(a16) == (_C.DKDV_256, 4) and ws(a16) == 4 * unit32(16384, 8)
+    # S = 32768 (34 GB of dS, the long-context case that used to drop to the 7-GEMM form): one K/V head's 4 query heads
+    # (4.3 GB) do not fit -> 16 chunks of 2 query heads of ONE K/V head, fp32 partials accumulated across the fractions
+    a32 = args(1, 32768, 32768, 32, 8, causal=True)
+    assert chunks(a32, 5 * GiB // 2) == (16, 1, 2, 2 * per(32768))
+    g = C.c_int32()
+    assert lib.rfa_bwd_plan(C.byref(a32), None, None, C.byref(g)) == 0 and g.value == 1          # still the 5-GEMM form
+    assert ws(a32) == plan(a32)[1] * unit32(32768, 8)
+    # MHA: chunks of whole heads; below one query head's share: the 7-GEMM form
+    assert chunks(args(1, 32768, 32768, 32, 32, causal=True), 5 * GiB // 2) == (16, 2, 1, 2 * per(32768))
+    assert chunks(args(1, 32768, 32768, 32, 8, causal=True), GiB // 2)[0] == 0
+    assert lib.rfa_bwd_ds_scratch_min_bytes(C.byref(args(1, 32768, 32768, 32, 8, causal=True))) == per(32768)
+    # two-phase (ring step) calls chunk by whole K/V heads only (their partials are not accumulated across launches)
+    assert chunks(args(1, 32768, 32768, 32, 8, causal=True, phases=_C.BWD_COMPUTE), 5 * GiB // 2)[0] == 0
+    assert chunks(args(1, 16384, 16384, 32, 8, causal=True, phases=_C.BWD_COMPUTE), 5 * GiB // 2) == (4, 2, 4, 8 * per(16384))
+    # head dim 256 has no chunked form
+    assert chunks(args(1, 8192, 8192, 16, 4, D=256, causal=True), GiB)[0] == 0
     # invalid plan fields are rejected
     bad = args(1, 64, 64, 1, 1, form=7)
     bad.dout = bad.q = bad.k = bad.v = bad.lse = bad.delta = bad.dq = bad.dk = bad.dv = 16

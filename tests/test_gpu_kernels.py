@@ -352,6 +352,79 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
     _check("dq spill vs recompute", res[True][0], res[False][0].float(), 0, kind="grad")
 
 
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,causal,cu", [
+    (1, 1024, 1024, 8, 2, True, None),          # GQA 4:1, dense causal (triangular scratch rows)
+    (2, 640, 896, 6, 6, False, None),           # MHA, batch, rectangular rows, ragged tiles
+    (3, 1100, 1100, 8, 4, True, [0, 300, 1400, 2100]),   # packed sequences
+])
+def test_ds_handoff_in_head_group_chunks(B, Sq, Sk, H, Hk, causal, cu):
+    """ABI 5: a dS scratch SMALLER than the whole hand-off does not switch the 5-GEMM backward off — the call runs it in
+    head-group chunks over the one buffer (include/rfa.h: ds_scratch_bytes): chunks of whole K/V heads, then fractions
+    of ONE K/V head's query heads whose dK/dV shares are accumulated in the fp32 partials.  Every chunking of a call
+    must reproduce the oracle — plain outputs and `+=` accumulators — and the 7-GEMM fall-back below one query head."""
+    import ctypes as C
+
+    from ring_flash_attn import _C, config
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * Sq + H)
+    D, scale = 128, 128 ** -0.5
+    if cu is None:
+        q, k, v, do = (torch.randn(B, s_, h_, D, generator=g).to(BF) for s_, h_ in ((Sq, H), (Sk, Hk), (Sk, Hk), (Sq, H)))
+        ro, rl, rdq, rdk, rdv = _oracle_dense(q, k, v, do, causal)
+        vl, pre = {}, {}
+        lse_shape = (B, H, Sq)
+    else:
+        T = cu[-1]
+        q, k, v, do = (torch.randn(T, h_, D, generator=g).to(BF) for h_ in (H, Hk, Hk, H))
+        cut = torch.tensor(cu, dtype=torch.int32)
+        ro, rl, rdq, rdk, rdv = _oracle_varlen(q, k, v, do, cut, cut, causal)
+        mx = int((cut[1:] - cut[:-1]).max())
+        vl = dict(cu_seqlens_q=cut.to(dev), cu_seqlens_k=cut.to(dev), max_seqlen_q=mx, max_seqlen_k=mx)
+        pre = dict(cu_seqlens_q=cut.to(dev), max_seqlen_q=mx)
+        lse_shape = (H, T)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out, lse = torch.empty_like(qd), torch.empty(lse_shape, dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse, **vl)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta, **pre)
+
+    def run(limit):
+        be.release_scratch()
+        with config.override(ds_spill_max_bytes=limit):
+            dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+            be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv, **vl)
+            dqa = torch.full(qd.shape, 2.0, dtype=torch.float32, device=dev)
+            dka = torch.full(kd.shape, -1.0, dtype=torch.float32, device=dev)
+            dva = torch.full(kd.shape, 0.5, dtype=torch.float32, device=dev)
+            be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq_acc=dqa, dk_acc=dka, dv_acc=dva, **vl)
+            pool = list(be._ds_pool.values())
+        be.release_scratch()
+        return (dq, dk, dv, dqa - 2.0, dka + 1.0, dva - 0.5), (pool[0].numel() if pool else 0)
+
+    # what the call asks for: the whole hand-off, one query head
+    a = _C.BwdArgs()
+    a.B, a.H, a.Hk, a.D, a.dtype, a.causal = (len(cu) - 1 if cu else B), H, Hk, D, 0, int(causal)
+    a.Sq, a.Sk = (mx, mx) if cu else (Sq, Sk)
+    a.total_k = kd.shape[0] if cu else B * Sk
+    if cu:
+        a.cu_seqlens_q = a.cu_seqlens_k = 1
+    full, per = be.lib.rfa_bwd_ds_scratch_bytes(C.byref(a)), be.lib.rfa_bwd_ds_scratch_min_bytes(C.byref(a))
+    assert full == H * per
+    G = H // Hk
+    limits = {"all heads": full, "whole K/V heads": per * G, "one query head": per, "below one head (7-GEMM)": per - 1}
+    if G > 2:
+        limits["half a group"] = per * (G // 2)
+    for name, limit in limits.items():
+        got, used = run(limit)
+        assert used == (0 if limit < per else limit), (name, used, limit)       # the ONE scratch is never larger than the limit
+        for nm, g_, r_ in zip(("dq", "dk", "dv", "dq_acc", "dk_acc", "dv_acc"), got, (rdq, rdk, rdv) * 2):
+            _check(f"{name}.{nm}", g_, r_, 0, kind="grad")
+
+
 @pytest.mark.parametrize("nsplit", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk", [
     (700, 700, True, 2, 4, 2),        # ragged tails, GQA, batch: key blocks of 256 with a 188-key tail
