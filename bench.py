@@ -421,57 +421,6 @@ def cpu_baseline(hk, full, fwd_only=False):
     }
 
 
-class ClockSampler:
-    """best-effort average shader clock during the timed region (MHz): a thread reading the amdgpu sysfs node
-    `freq1_input` (sclk, Hz) of this rank's device every 20 ms.  None where the node is missing or unreadable.  The
-    roofline fraction is quoted against the 2.4 GHz peak; the chip clocks to its power budget (MI355X_MICROARCH.md,
-    "DVFS give-back"), so the line also says at what clock the kernels actually ran."""
-
-    def __init__(self, index):
-        import glob
-        import threading
-
-        self.paths = []
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/freq1_input"))
-        if cards:
-            self.paths = [cards[index % len(cards)]]
-        self.samples, self._stop, self._thr = [], threading.Event(), None
-
-    def _read(self):
-        for p_ in self.paths:
-            try:
-                with open(p_) as f:
-                    return float(f.read().strip()) / 1e6
-            except (OSError, ValueError):
-                return None
-        return None
-
-    def __enter__(self):
-        import threading
-
-        if self.paths and self._read() is not None:
-            def loop():
-                while not self._stop.wait(0.02):
-                    v = self._read()
-                    if v:
-                        self.samples.append(v)
-            self._thr = threading.Thread(target=loop, daemon=True)
-            self._thr.start()
-        return self
-
-    def __exit__(self, *exc):
-        self._stop.set()
-        if self._thr is not None:
-            self._thr.join(timeout=1.0)
-
-    def report(self):
-        if not self.samples:
-            return None
-        return {"avg_mhz": sum(self.samples) / len(self.samples), "min_mhz": min(self.samples), "max_mhz": max(self.samples),
-                "samples": len(self.samples), "peak_mhz": 2400.0,
-                "source": "amdgpu hwmon freq1_input (sclk), 20 ms period, over the timed region"}
-
-
 def cpu_baseline_ring(world, hk, budget_s, fwd_only=False):
     """N > 1: the zigzag schedule on the host — `world` gloo CPU processes (cores / world threads each) run one
     forward + backward of zigzag_ring_flash_attn_func with the CPU oracle as their attention arithmetic
@@ -721,8 +670,7 @@ def main():
     for _ in range(args.warmup):
         step()
     counter[0] = 0
-    with ClockSampler(local_rank) as clock:
-        elapsed = timed(args.steps)
+    elapsed = timed(args.steps)
 
     ms = elapsed / args.steps * 1e3
     its = args.steps / elapsed
@@ -755,7 +703,6 @@ def main():
             "world_size": world,
             "forward_only": fwd_only,
         },
-        "clock": clock.report(),
         "algorithmic_tflops_per_gpu": per_gpu_flops * its / 1e12,
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
     }
@@ -931,9 +878,11 @@ def main():
                 "traffic_source": note,
                 "avg_launch_ms": t_in[dom],
                 "timed": "in-step" if in_step_line else "isolated launches of the local block",
-                "clock_avg_mhz": (result["clock"] or {}).get("avg_mhz"),
-                # issue-side counters and the clock of the PROFILED passes of the same build (profiles/collect_pmc.sh):
-                # wave cycles / busy fractions say whether a change saved cycles or only moved the clock
+                # issue-side counters and the effective shader clock (GRBM_GUI_ACTIVE / kernel duration) of the PROFILED
+                # passes of the same build (profiles/collect_pmc.sh): the fraction above is quoted against the 2.4 GHz
+                # peak while the chip clocks to its power budget; wave cycles / busy fractions say whether a change saved
+                # cycles or only moved the clock.  (The amdgpu sysfs / rocm-smi sclk nodes report a coarse DPM level —
+                # 1403 MHz under this load, 95 MHz from rocm-smi — not the clock the kernels run at: measured, not used.)
                 "profiled": ({k_: entry[k_] for k_ in ("effective_clock_ghz_profiled", "mfma_pipe_busy", "sq_wave_cycles",
                                                        "sq_active_inst_any", "sq_wait_any", "sq_wait_inst_any") if k_ in entry}
                              if entry else None),

@@ -248,10 +248,12 @@ class HipBackend:
         ONE buffer per (device, stream), kept and reused by every backward on that stream (kernels of one stream run in
         order, so the next backward's dK/dV kernel cannot start before this one's dQ kernel has read the blocks) —
         no 2 GB allocation per backward, and peak memory independent of the head count and the sequence length: the
-        buffer is at most config.ds_spill_max_bytes (default 2.5 GiB: the headline's 2.0 GiB hand-off in one piece) and,
+        buffer is at most config.ds_spill_max_bytes (default 4.5 GiB; the headline's hand-off is 2.0 GiB and takes just that) and,
         when it is first taken or has to grow, at most config.ds_spill_max_frac (0.5) of the memory free at that moment;
         a hand-off that does not fit runs in head-group chunks over it (include/rfa.h: ds_scratch_bytes; long contexts
-        keep the 5-GEMM form).  A hand-off whose smallest chunk does not fit, or an allocation failure, falls back to
+        keep the 5-GEMM form — measured at S = 32768, 32 heads, 34 GB of dS: 942 TFLOP/s in 8 chunks of 4 query heads
+        against 950 with the whole hand-off resident and 895 for the 7-GEMM form; chunks of 2 query heads — a 2.5 GiB
+        limit — give the dQ kernel only one workgroup per CU and fall to 848, which is why the default is not smaller).  A hand-off whose smallest chunk does not fit, or an allocation failure, falls back to
         the 7-GEMM form instead of failing a backward that would have fitted without it (logged once).
         `release_scratch()` returns the buffers."""
         full = self.lib.rfa_bwd_ds_scratch_bytes(C.byref(a))

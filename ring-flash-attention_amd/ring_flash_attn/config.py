@@ -20,7 +20,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | kv_keep_total_bytes       | RFA_ZIGZAG_KV_KEEP_TOTAL_BYTES  | 4 GiB   | ... or all live kept buffers of the process together would (L layers x W x (K,V)) |
 | llama3_gather_max_bytes   | RFA_LLAMA3_GATHER_MAX_BYTES     | 1 GiB   | llama3: head groups fused per collective while the gathered K/V stay below |
 | bwd_ds_spill              | RFA_BWD_DS_SPILL                | 1       | 5-GEMM backward (dS hand-off) where eligible; 0: always the 7-GEMM form |
-| ds_spill_max_bytes        | RFA_DS_SPILL_MAX_BYTES          | 2.5 GiB | size of the ONE reusable dS scratch per device and stream; larger hand-offs run in head-group chunks |
+| ds_spill_max_bytes        | RFA_DS_SPILL_MAX_BYTES          | 4.5 GiB | size of the ONE reusable dS scratch per device and stream; larger hand-offs run in head-group chunks |
 | ds_spill_max_frac         | RFA_DS_SPILL_MAX_FRAC           | 0.5     | ... and never more than this fraction of the memory free when it is first taken |
 | fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 / 4x64 |
 | dkdv_wide, dkdv_nsplit    | RFA_DKDV_WIDE, RFA_DKDV_NSPLIT  | unset   | dK/dV launch plan overrides (tuning / tests) |
@@ -82,7 +82,7 @@ class Config:
     kv_keep_total_bytes: int = 4 * _GiB
     llama3_gather_max_bytes: int = 1 * _GiB
     bwd_ds_spill: bool = True
-    ds_spill_max_bytes: int = 5 * _GiB // 2
+    ds_spill_max_bytes: int = 9 * _GiB // 2
     ds_spill_max_frac: float = 0.5
     fwd_form: str = "auto"
     dkdv_wide: int = -1          # -1 unset, 0 the 128-key form, 1 the 256-key form
