@@ -52,14 +52,15 @@ inline bool drop_args_ok(float p, int window, int wl, int wr, int causal) {
 
 }  // namespace
 
-// forward kernel form: the 4 x 64 form covers head dim 128 without window / dropout
-#ifndef RFA_FWD_DEFAULT_4x64
-#define RFA_FWD_DEFAULT_4x64 0
+// forward kernel form.  The 4 x 64 form (one wave per SIMD, 64 query rows per wave: csrc/experiments/rfa_fwd64.hip) was
+// measured 7 - 13 % slower than the 8 x 32 form in two rounds and is NOT part of the default build any more
+// (build.py --with-fwd64 compiles it in, -DRFA_WITH_FWD64=1); without it a call that asks for it by name is refused.
+#ifndef RFA_WITH_FWD64
+#define RFA_WITH_FWD64 0
 #endif
 static bool fwd_use_4x64(const rfa_fwd_args* a) {
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if (a->D != kHeadDim || win || a->dropout_p > 0.f) return false;
-  if (a->fwd_form == RFA_FWD_AUTO) return RFA_FWD_DEFAULT_4x64 != 0;
   return a->fwd_form == RFA_FWD_4x64;
 }
 
@@ -128,11 +129,25 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.drop_scale = drop_rescale(a->dropout_p);
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
-  const int rows = fwd_qrows_per_block();
-  p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;       // (both forms: 256 rows per workgroup)
+  // 256 query rows per workgroup (8 waves) — or 128 (4 waves, two workgroups per CU) when the 8-wave grid would leave
+  // most of the 256 CUs without a workgroup (short per-rank chunks, few heads: llama3 head groups, the HF adapter)
+  int rows = fwd_qrows_per_block();
+  {
+    const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
+    const int64_t wgs8 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + rows - 1) / rows);
+    if ((a->D == kHeadDim || a->D == kHeadDim / 2) && !win && !(a->dropout_p > 0.f) && wgs8 < 384 &&
+        a->fwd_form == RFA_FWD_AUTO)                        // (RFA_FWD_8x32 by name: always the 256-row form)
+      rows = 128;
+  }
+  p.qrows = rows;
+  p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
   if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x64) return RFA_ERR_ARGS;
   if (a->D > kHeadDim) return launch_status(launch_fwd_big(p, a->dtype, (hipStream_t)stream));
+#if RFA_WITH_FWD64
   if (fwd_use_4x64(a)) return launch_status(launch_fwd64(p, a->dtype, (hipStream_t)stream));
+#else
+  if (fwd_use_4x64(a)) return RFA_ERR_ARGS;             // the experiment is not in this build
+#endif
   return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
 }
 

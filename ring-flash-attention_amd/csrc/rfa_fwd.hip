@@ -38,12 +38,11 @@ namespace rfa {
 #ifndef RFA_FWD_X_LOAD
 #define RFA_FWD_X_LOAD 1
 #endif
-#ifndef RFA_FWD_WAVES
-#define RFA_FWD_WAVES 8      // waves per workgroup (32 q rows each); 4 -> two independent workgroups per CU
-#endif
-constexpr int kFwdWaves = RFA_FWD_WAVES;
-constexpr int kFwdThreads = kFwdWaves * 64;
-constexpr int kFwdQRows = kFwdWaves * 32;   // query rows per workgroup
+// waves per workgroup (32 q rows each) are a template parameter kW of the kernel: 8 (256 query rows, one workgroup per
+// CU) is the tuned form; 4 (128 rows, two independent workgroups per CU) is launched when the 8-wave grid would leave
+// the chip under-filled — twice the workgroups, half the K/V tile reuse (measured: (B 1, S 2048, 16 heads) 0.050 ->
+// 0.040 ms, (B 8, S 1024, 32 heads) 0.117 -> 0.111 ms, but S >= 4096 at 32 heads 3 - 6 % slower; rfa_api.cpp picks)
+constexpr int kFwdWavesMax = 8;
 #ifndef RFA_FWD_KV
 #define RFA_FWD_KV 64        // keys per tile (64 | 128): 128 halves the barriers / DMA waits per MFMA at twice the LDS and 32 more registers
 #endif
@@ -61,8 +60,9 @@ template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * kD
 // kD: compiled head dim (128 or 64: half the MFMAs, half the LDS bytes per tile); kFullD: D == kD (LDS-DMA
 // staging, no conditional loads), otherwise D < kD is zero padded through the register staging path
 // kDrop: dropout on the probabilities that enter P·V (instances without a window only)
-template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
-__global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) {
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false, int kW = kFwdWavesMax>
+__global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
+  constexpr int kFwdWaves = kW, kFwdThreads = kW * 64, kFwdQRows = kW * 32;   // (query rows per workgroup)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   // LDS map: K stages at [0, stages*tile), V stages behind them
@@ -471,14 +471,22 @@ __global__ __launch_bounds__(kFwdThreads, 2) void fwd_kernel(const FwdParams p) 
   }
 }
 
-template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
-static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false, int kW = kFwdWavesMax>
+static int launch_fwd_w(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin, kDrop>, fwd_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin, kDrop, kW>, fwd_smem<kD>(), attr_done)) return rc;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin, kDrop>), dim3((unsigned)nblocks), dim3(kFwdThreads), fwd_smem<kD>(), stream, p);
+  hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin, kDrop, kW>), dim3((unsigned)nblocks), dim3(kW * 64), fwd_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
+}
+template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
+static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
+  // the 128-row form exists for the LDS-DMA instances without window / dropout (rfa_api.cpp: fwd_rows_for)
+  if constexpr (kFullD && !kWin && !kDrop) {
+    if (p.qrows == 128) return launch_fwd_w<T, kD, kFullD, kWin, kDrop, 4>(p, stream);
+  }
+  return launch_fwd_w<T, kD, kFullD, kWin, kDrop, kFwdWavesMax>(p, stream);
 }
 
 template <typename T, bool kWin, bool kDrop>
@@ -497,6 +505,6 @@ int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
   return dtype == 0 ? launch_fwd_d<bf16_t, false, false>(p, stream) : launch_fwd_d<f16_t, false, false>(p, stream);
 }
 
-int fwd_qrows_per_block() { return kFwdQRows; }
+int fwd_qrows_per_block() { return kFwdWavesMax * 32; }
 
 }  // namespace rfa

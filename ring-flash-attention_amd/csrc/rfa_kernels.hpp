@@ -46,6 +46,7 @@ struct FwdParams {
   int wl, wr;          // visible keys of query i: i + (Sk - Sq) - wl <= j <= i + (Sk - Sq) + wr; -1 = unbounded
                        // (causal is folded in by the API layer: wr = 0)
   int nqblk;
+  int qrows;           // query rows per workgroup the launch was sized for: 256 (8 waves) or 128 (4 waves, small grids)
   float scale;
   // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
   // the offsets that turn local (head, query position, key position) into global ones

@@ -733,38 +733,53 @@ def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
 
 
 # ------------------------------------------------------------------------------------------------------------
-# the 4 x 64 forward form (csrc/rfa_fwd64.hip, opt-in: RFA_FWD_FORM=4x64 / rfa_fwd_args.fwd_form)
-@pytest.mark.parametrize("B,Sq,Sk,H,Hk,causal,dtype", [
-    (1, 1000, 1000, 4, 2, True, BF),            # odd tile count of the last workgroup, masked tails
-    (2, 300, 777, 2, 2, True, BF),              # bottom-right aligned, odd number of key tiles
-    (1, 513, 513, 2, 1, False, BF),             # one valid row in the last workgroup
-    (1, 256, 64, 1, 1, False, BF),              # a single key tile
-    (1, 900, 260, 2, 2, True, torch.float16),   # queries without any visible key (lse = +inf), fp16 MFMAs
+# the 128-row (4-wave) forward form: picked by the library for grids that would leave the chip under-filled
+# (csrc/rfa_api.cpp: fewer than 384 workgroups of 256 rows); RFA_FWD_FORM=8x32 forces the 256-row form
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal,dtype", [
+    (1, 1000, 1000, 4, 2, 128, True, BF),            # odd tile count of the last workgroup, masked tails
+    (2, 300, 777, 2, 2, 128, True, BF),              # bottom-right aligned, odd number of key tiles
+    (1, 513, 513, 2, 1, 128, False, BF),             # one valid row in the last 128-row workgroup
+    (1, 2048, 2048, 16, 8, 128, True, BF),           # the llama3 head-group regime the form exists for (128 workgroups of 256 rows)
+    (1, 900, 260, 2, 2, 128, True, torch.float16),   # queries without any visible key (lse = +inf), fp16 MFMAs
+    (1, 1500, 1500, 4, 4, 64, True, BF),             # head dim 64 instance
 ])
-def test_fwd_4x64_form_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, causal, dtype):
+def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq, Sk, H, Hk, D, causal, dtype):
+    """both forward forms on grids below the threshold: against the oracle, and against each other BIT FOR BIT (a wave's
+    32 rows do not depend on how many waves share its workgroup) — plain outputs and the fused merge epilogue"""
     from oracle import flash_attn_ref as O
     from ring_flash_attn.backend import get_backend, set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
-    monkeypatch.setenv("RFA_FWD_FORM", "4x64")
     g = torch.Generator().manual_seed(Sq + Sk)
-    q = torch.randn(B, Sq, H, 128, generator=g).to(dtype)
-    k = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
-    v = torch.randn(B, Sk, Hk, 128, generator=g).to(dtype)
+    q = torch.randn(B, Sq, H, D, generator=g).to(dtype)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(dtype)
     if Sq == 1000:                                   # spike keys: the deferred-rescale branch in the middle of the loop
         k[0, 300] = q[0, 400, 0:2] * 3.0
-    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, 128 ** -0.5, causal)
-    out = torch.empty(B, Sq, H, 128, dtype=dtype, device=dev)
-    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
-    be.fwd(q.to(dev), k.to(dev), v.to(dev), softmax_scale=128 ** -0.5, causal=causal, out=out, lse=lse)
-    _check("4x64.out", out, ro, 0, kind="out")
-    _check("4x64.lse", lse, rl, 0, kind="lse")
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, D ** -0.5, causal)
+    res = {}
+    for form in ("auto", "8x32"):
+        monkeypatch.setenv("RFA_FWD_FORM", form)
+        out = torch.empty(B, Sq, H, D, dtype=dtype, device=dev)
+        lse = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+        be.fwd(q.to(dev), k.to(dev), v.to(dev), softmax_scale=D ** -0.5, causal=causal, out=out, lse=lse)
+        acc = torch.zeros(B, Sq, H, D, dtype=torch.float32, device=dev)
+        lacc = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+        half = Sk // 2
+        be.fwd(q.to(dev), k.to(dev)[:, :half], v.to(dev)[:, :half], softmax_scale=D ** -0.5, causal=False, out_acc=acc, lse_acc=lacc, acc_init=True)
+        be.fwd(q.to(dev), k.to(dev)[:, half:], v.to(dev)[:, half:], softmax_scale=D ** -0.5, causal=False, out_acc=acc, lse_acc=lacc)
+        res[form] = (out, lse, acc, lacc)
+        _check(f"{form}.out", out, ro, 0, kind="out")
+        _check(f"{form}.lse", lse, rl, 0, kind="lse")
+    for a_, b_ in zip(res["auto"], res["8x32"]):
+        assert torch.equal(a_, b_)
 
 
-def test_fwd_4x64_form_in_the_schedules(single_rank_group, monkeypatch):
+def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
     """packed sequences, half-sequence selectors and the fused fp32 merge epilogue: the zigzag varlen schedule forced
-    onto its multi-step path (RFA_TEST_FORCE_STEPS) with the 4 x 64 forward form, against the 8 x 32 form"""
+    onto its multi-step path (RFA_TEST_FORCE_STEPS) with the library's choice of the forward form (128 rows on this
+    grid) against the 256-row form: identical bits"""
     import ring_flash_attn as R
 
     dev = _dev()
@@ -775,9 +790,8 @@ def test_fwd_4x64_form_in_the_schedules(single_rank_group, monkeypatch):
     k = torch.randn(2240, 2, 128, generator=g).to(BF).to(dev)
     v = torch.randn(2240, 2, 128, generator=g).to(BF).to(dev)
     res = {}
-    for form in ("8x32", "4x64"):
+    for form in ("8x32", "auto"):
         monkeypatch.setenv("RFA_FWD_FORM", form)
         out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(q, k, v, cu, 1120, causal=True, return_attn_probs=True)
         res[form] = (out.float().cpu(), lse.cpu())
-    _check("4x64 vs 8x32 out", res["4x64"][0], res["8x32"][0], 0, kind="out")
-    _check("4x64 vs 8x32 lse", res["4x64"][1], res["8x32"][1], 0, kind="lse")
+    assert torch.equal(res["auto"][0], res["8x32"][0]) and torch.equal(res["auto"][1], res["8x32"][1])

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ring-flash-attention_amd", "csrc")
-SRCS = ["rfa_fwd.hip", "rfa_fwd64.hip", "rfa_bwd.hip", "rfa_bigd.hip", "rfa_dqs.hip", "rfa_aux.hip"]
+SRCS = ["rfa_fwd.hip", "rfa_bwd.hip", "rfa_bigd.hip", "rfa_dqs.hip", "rfa_aux.hip"]
 
 
 def main():
