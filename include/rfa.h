@@ -217,6 +217,10 @@ typedef struct {
    * (S = 32768, 32 heads: 34 GB of dS) keep the 5-GEMM form (rfa_bwd_ds_chunks() reports the chunking; head dim 128
    * only; a buffer below one query head's share, rfa_bwd_ds_scratch_min_bytes(), falls back to the 7-GEMM form). */
   int64_t ds_scratch_bytes;
+  /* ABI 5, varlen: number of packed q rows addressed (Tq); 0 = total_k.  Sizes the packed layout of ds_scratch:
+   * H * (total_q / 32 + B) * ceil(max_seqlen_k / 32) blocks of 2 KiB — bounded by the packed row count, not by
+   * B x the longest sequence. */
+  int64_t total_q;
 } rfa_bwd_args;
 
 enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };
@@ -266,8 +270,9 @@ int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
 /* the launch plan of a call: *form = RFA_DKDV_128 / RFA_DKDV_256, *nsplit >= 1, *five_gemm = 1 when the call
  * (with its ds_scratch) runs the dS-spill form.  Pure function of the arguments. */
 int rfa_bwd_plan(const rfa_bwd_args *args, int32_t *form, int32_t *nsplit, int32_t *five_gemm);
-/* bytes of ds_scratch the call would use (B*H*ceil(Sq/32)*ceil(Sk/32)*2048; packed input: B sequences, Sq / Sk =
- * max_seqlen_q / _k; with q_half / k_half: ceil(S/2) instead of S), or 0 if it is not eligible */
+/* bytes of ds_scratch the whole hand-off of the call uses — dense: B*H*ceil(Sq/32)*ceil(Sk/32)*2048 (dense causal: the
+ * visited triangle only); packed input: H*(total_q/32 + B)*ceil(max_seqlen_k/32)*2048; with q_half / k_half: ceil(S/2)
+ * instead of S — or 0 if it is not eligible */
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args *args);
 /* the smallest ds_scratch with which the call still runs the 5-GEMM form (one query head's dS; 0: not eligible) */
 int64_t rfa_bwd_ds_scratch_min_bytes(const rfa_bwd_args *args);

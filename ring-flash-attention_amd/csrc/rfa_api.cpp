@@ -255,10 +255,20 @@ static int bwd_ds_c(const rfa_bwd_args* a) {
   return c > nkb ? nkb : c;
 }
 
+// blocks of the dS scratch per head: dense = one (batch, head) — rows rectangular or packed triangular —, packed
+// (cu_seqlens) = ALL sequences of a head: total_q / 32 + B rows of ceil(max_seqlen_k / 32) blocks (rfa_kernels.hpp:
+// ds_rowpart — bounded by the packed row count instead of B x the longest sequence)
+static int64_t bwd_ds_head_blocks(const rfa_bwd_args* a) {
+  const int nkb = ds_blocks(a->Sk, a->k_half);
+  if (a->cu_seqlens_q != nullptr) {
+    const int64_t tq = a->total_q > 0 ? a->total_q : a->total_k;
+    return ((tq >> 5) + a->B) * (int64_t)nkb;
+  }
+  return ds_row_off(ds_blocks(a->Sq, a->q_half), nkb, bwd_ds_c(a), 1);
+}
 // dS bytes of ONE query head (all batches / packed sequences)
 static int64_t bwd_ds_head_bytes(const rfa_bwd_args* a) {
-  const int64_t per_head = ds_row_off(ds_blocks(a->Sq, a->q_half), ds_blocks(a->Sk, a->k_half), bwd_ds_c(a), 1);
-  return (int64_t)a->B * per_head * kDsBlockBytes;
+  return (a->cu_seqlens_q != nullptr ? 1 : (int64_t)a->B) * bwd_ds_head_blocks(a) * kDsBlockBytes;
 }
 
 int64_t rfa_bwd_ds_scratch_bytes(const rfa_bwd_args* a) {
@@ -427,6 +437,8 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
       p.ds = a->ds_scratch;
       p.ds_c = bwd_ds_c(a);
       p.ds_tri = p.ds_c < ds_blocks(a->Sk, a->k_half) ? 1 : 0;
+      p.ds_packed = a->cu_seqlens_q != nullptr ? 1 : 0;
+      p.ds_head_blocks = bwd_ds_head_blocks(a);
       const int nfrac = Gfull / chunks.gc;
       const int64_t kv_esz = p.kv_f32 ? 4 : 2;
       for (int c = 0; c < chunks.nchunks; ++c) {

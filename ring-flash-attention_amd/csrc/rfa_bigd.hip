@@ -751,8 +751,8 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const bool spill = kWhich == 1 && p.ds != nullptr;
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
   const int ds_nkb = ds_blocks(p.Sk, p.k_half);
-  const int64_t ds_head_bytes = spill ? ds_row_off(ds_blocks(p.Sq, p.q_half), ds_nkb, p.ds_c, 1) * kDsBlockBytes : 0;
-  const char* ds_b = spill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
+  const int64_t ds_head_bytes = spill ? p.ds_head_blocks * kDsBlockBytes : 0;
+  const char* ds_b = spill ? (const char*)p.ds + ds_base_blocks(p, b) * kDsBlockBytes : nullptr;
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kBgRows / 32) + wave);
 
   wait_all_vmem();                                     // K_w / V_w: nothing the compiler tracks stays pending into the loop
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
       {
         const vec8<T> pb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
         if (spill) {
-          const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes + (ds_row_off(j, ds_nkb, p.ds_c, 1) + ds_kb) * kDsBlockBytes;
+          const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes + (ds_rowpart(p, j, (qs.row0 >> 5) + b, ds_nkb) + ds_kb) * kDsBlockBytes;
           const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rb, ds_lane, 0, 2);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[1]), rb, ds_lane + 128, 0, 2);

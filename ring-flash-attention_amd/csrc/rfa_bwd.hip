@@ -629,8 +629,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
   const int ds_nkb = ds_blocks(p.Sk, p.k_half);  // extents of the longest (half) sequence (= lk, lq when dense): rfa_dqs.hip
   // rows of the scratch: rectangular (p.ds_c >= ds_nkb) or packed triangular (dense causal), rfa_kernels.hpp
-  const int64_t ds_head_bytes = ds_row_off(ds_blocks(p.Sq, p.q_half), ds_nkb, p.ds_c, 1) * kDsBlockBytes;
-  const char* ds_b = kSpill ? (const char*)p.ds + (int64_t)b * p.H * ds_head_bytes : nullptr;
+  const int64_t ds_head_bytes = p.ds_head_blocks * kDsBlockBytes;
+  const char* ds_b = kSpill ? (const char*)p.ds + ds_base_blocks(p, b) * kDsBlockBytes : nullptr;
+  const int64_t ds_g0 = (qs.row0 >> 5) + b;            // packed layout: global index of this (half) sequence's first row
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kKeys / 32) + kbw);
 
   // dropout: this lane's key position; the mask word of (query i, key j) is word(i, j >> 2), byte j & 3
@@ -663,8 +664,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
     bool active = false;
     // dS scratch rows of this tile's two sub-tiles (wave-uniform; once per tile, outside the MFMA blocks)
-    const int64_t ds_roff0 = kSpill ? ds_row_off(2 * j, ds_nkb, p.ds_c, 1) : 0;
-    const int ds_rlen0 = kSpill ? ds_row_len(2 * j, ds_nkb, p.ds_c, 1) : 0;
+    const int64_t ds_roff0 = kSpill ? ds_rowpart(p, 2 * j, ds_g0, ds_nkb) : 0;
+    const int ds_rlen0 = kSpill ? ds_rowlen(p, 2 * j, ds_nkb) : 0;
     // parity form: the one sub-tile t = par; kWide: both, one after the other (the sub-tile lives in address
     // bit 13 of the Q/dO fragment bases and bit 7 of the statistics base: toggled, not re-computed)
 #if RFA_KV_WIDE_UNROLL

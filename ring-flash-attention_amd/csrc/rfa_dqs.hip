@@ -99,14 +99,14 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   // scratch layout: (b, h, qt, kb) with the extents of the LONGEST sequence (p.Sq, p.Sk = max_seqlen for packed
   // input; = the sequence length when dense), of which this sequence uses the first ceil(lk / 32) key blocks of
   // its first ceil(lq / 32) rows of blocks
-  const int nQt = ds_blocks(p.Sq, p.q_half), nKb = ds_blocks(p.Sk, p.k_half);
+  const int nKb = ds_blocks(p.Sk, p.k_half);
   // this wave's run of dS blocks: (b, h, qt = qw0 / 32, kb = 0 .. ceil(lk/32)-1), contiguous
   // (rows are rectangular, p.ds_c >= nKb, or packed triangular for dense causal calls: rfa_kernels.hpp)
   const int qt = qw0 >> 5;
-  const char* srun = (const char*)p.ds + (((int64_t)b * p.H + h) * ds_row_off(nQt, nKb, p.ds_c, 1) +
-                                          ds_row_off(qt, nKb, p.ds_c, 1)) * (int64_t)kDsBlockBytes;
+  const char* srun = (const char*)p.ds + (ds_base_blocks(p, b) + (int64_t)h * p.ds_head_blocks +
+                                          ds_rowpart(p, qt, (qs.row0 >> 5) + b, nKb)) * (int64_t)kDsBlockBytes;
   int run = (lk + 31) >> 5;                              // blocks of this row that can hold data
-  const int rlen = ds_row_len(qt, nKb, p.ds_c, 1);
+  const int rlen = ds_rowlen(p, qt, nKb);
   run = run < rlen ? run : rlen;
   const dma_rsrc_t rs = make_dma_rsrc(srun, qw0 < lq ? run * kDsBlockBytes : 0);
 

@@ -81,6 +81,8 @@ struct BwdParams {
   int kv_f32;          // dk / dv point to fp32 buffers (overwritten), strides in fp32 elements
   void* ds;            // dS spill scratch (rfa_dqs.hip) or nullptr: dkdv_kernel stores its packed dS blocks there
   int ds_tri, ds_c;    // scratch rows are triangular (dense causal calls): row qt holds key blocks 0 .. min(nKb, qt + ds_c) - 1
+  int ds_packed;       // packed (cu_seqlens) layout of the scratch: [head][global query-block row][key block], see ds_rowpart()
+  int64_t ds_head_blocks;   // blocks per head (dense: per (batch, head))
   int nqblk, nkblk;
   float scale;
   // 256-key dK/dV form (dkdv_kernel kWide): the tile range of a key block is shared by nsplit workgroups; split s
@@ -161,6 +163,23 @@ __host__ __device__ inline int64_t ds_row_off(int qt, int nKb, int c, int tri) {
   const int64_t n1 = e1 > iA ? e1 - iA : 0;
   const int64_t n2 = qt > iB ? qt - iB : 0;
   return n1 * (iA + c) + n1 * (n1 - 1) / 2 + n2 * nKb;
+}
+// Where the dS blocks of query-block row qt (counted inside its (half) sequence) live, in blocks from the scratch base:
+//     ds_base_blocks(p, b) + hc * p.ds_head_blocks + ds_rowpart(p, qt, g0, nKb)          (hc: head index inside the launch)
+//   dense:  [batch][head][rows], rows rectangular or packed triangular (ds_row_off above);
+//   packed: [head][g][nKb] with the GLOBAL row index g = g0 + qt, g0 = (first packed row of the (half) sequence >> 5)
+//           + sequence index — unique per (sequence, row) because ceil(len / 32) <= floor(end / 32) - floor(start / 32) + 1.
+//           The scratch then holds total_q / 32 + B rows per head instead of B x max_seqlen / 32: bounded by the PACKED
+//           row count whatever the mix of sequence lengths (one long and two short sequences used to cost three
+//           times the longest: 10.5 GB instead of 3.9 GB for the varlen benchmark's second pattern).
+__host__ __device__ inline int64_t ds_base_blocks(const BwdParams& p, int b) {
+  return p.ds_packed ? 0 : (int64_t)b * p.H * p.ds_head_blocks;
+}
+__host__ __device__ inline int64_t ds_rowpart(const BwdParams& p, int qt, int64_t g0, int nKb) {
+  return p.ds_packed ? (g0 + qt) * (int64_t)nKb : ds_row_off(qt, nKb, p.ds_c, 1);
+}
+__host__ __device__ inline int ds_rowlen(const BwdParams& p, int qt, int nKb) {
+  return p.ds_packed ? nKb : ds_row_len(qt, nKb, p.ds_c, 1);
 }
 int bwd_dq_rows_per_block();
 int bwd_dkdv_keys_per_block(bool wide);

@@ -88,6 +88,7 @@ class BwdArgs(C.Structure):
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
         ("ds_scratch_bytes", C.c_int64),
+        ("total_q", C.c_int64),
     ]
 
 

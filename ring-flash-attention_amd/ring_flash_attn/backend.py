@@ -176,7 +176,7 @@ class HipBackend:
             a.H, a.D = q.shape[1], q.shape[2]
             a.Hk = k.shape[1]
             a.Sq, a.Sk = int(max_seqlen_q), int(max_seqlen_k)
-            a.total_k = k.shape[0]
+            a.total_k, a.total_q = k.shape[0], q.shape[0]
         else:
             a.B, a.Sq, a.H, a.D = q.shape
             a.Sk, a.Hk = k.shape[1], k.shape[2]

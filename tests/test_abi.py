@@ -261,11 +261,12 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 1024, 1024, 4, 2)) == 0
     assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
     assert ws(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0 and ds(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0
-    # packed sequences: the form is chosen from the packed row count, the scratch (rectangular rows, also when
-    # causal) from the longest sequence; half-sequence steps reserve half the blocks per axis
+    # packed sequences: the form is chosen from the packed row count, and so is the scratch (ABI 5): total / 32 + B
+    # query-block rows per head, each with the key blocks of the longest (half) sequence — 3.9 GB for the varlen
+    # benchmark's (256, 7392, 544) pattern where B x the longest sequence would be 10.5 GB
     assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit32(8192, 8)
-    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True)) == 3 * 32 * 231 * 231 * 2048
-    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 3 * 32 * 116 * 116 * 2048
+    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True)) == 32 * (256 + 3) * 231 * 2048
+    assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 32 * (256 + 3) * 116 * 2048
     # the overrides are arguments ...
     assert ws(args(1, 8192, 8192, 32, 8, form=_C.DKDV_128)) == 0
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == (_C.DKDV_256, 3)
