@@ -27,6 +27,10 @@
 #ifndef RFA_FWD_AHEAD
 #define RFA_FWD_AHEAD 4
 #endif
+// (Round 4: a software-pipelined tile loop — S of tile j+1 issued inside the softmax of tile j in every wave, two S
+//  register sets, the guide's "att[2]" technique — was built here and removed again: it needs 32 more registers than
+//  the 256 a wave of this 2-waves-per-SIMD kernel has; hipcc then keeps the Q fragments in scratch and reloads them
+//  for every tile: numerically identical, 0.54 -> 1.50 ms.  DESIGN.md section 7.)
 #ifndef RFA_FWD_PACKED_VALU
 #define RFA_FWD_PACKED_VALU 0   // 1: scale / subtract / row sum as v_pk_fma_f32 / v_pk_add_f32 (22 instructions fewer per
                                 // tile pair, but 17 v_mov per tile to pair registers and 235 instead of 218 VGPRs:

@@ -313,7 +313,7 @@ static void run_case(const Case& c, uint64_t seed) {
   ba.delta = ddelta; ba.delta_batch = fa.lse_batch; ba.delta_head = fa.lse_head;
   ba.dq = gdq; ba.dk = gdk; ba.dv = gdv; ba.dq_st = fa.q_st; ba.dk_st = fa.k_st; ba.dv_st = fa.k_st;
   ba.cu_seqlens_q = dcuq; ba.cu_seqlens_k = dcuk;
-  ba.B = B; ba.H = H; ba.Hk = Hk; ba.D = D; ba.Sq = Sq; ba.Sk = Sk; ba.total_k = Tk;
+  ba.B = B; ba.H = H; ba.Hk = Hk; ba.D = D; ba.Sq = Sq; ba.Sk = Sk; ba.total_k = Tk; ba.total_q = Tq;
   ba.softmax_scale = scale; ba.causal = c.causal; ba.dtype = RFA_BF16;
   void* ws = nullptr;
   const int64_t wsb = rfa_bwd_workspace_bytes(&ba);
