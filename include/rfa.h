@@ -127,9 +127,20 @@ typedef struct {
   int64_t q_pos_offset, k_pos_offset;
   int32_t head_offset;
   /* Kernel form (tuning / tests; 0 = chosen by the library): RFA_FWD_8x32 = 8 waves x 32 query rows, two waves per SIMD
-   * (csrc/rfa_fwd.hip: every head dim, windows, dropout); RFA_FWD_4x64 = 4 waves x 64 rows, one wave per SIMD with O
-   * and Q in the accumulator registers (csrc/rfa_fwd64.hip: head dim 128 without window / dropout; ignored otherwise) */
+   * (csrc/rfa_fwd.hip: every head dim, windows, dropout; 256 query rows per workgroup — RFA_FWD_AUTO also launches the
+   * same kernel with 4 waves / 128 rows on grids that would under-fill the chip); RFA_FWD_4x64 = 4 waves x 64 rows, one
+   * wave per SIMD (csrc/experiments/rfa_fwd64.hip: only in builds made with --with-fwd64, RFA_ERR_ARGS otherwise) */
   int32_t fwd_form;
+  /* ABI 5 — split-KV launches.  A call with few query rows and many keys (a llama3 head group at 2048 tokens per rank
+   * against the gathered keys of 8 ranks: 256 key tiles per workgroup, half the CUs without one) is launched with the
+   * key tiles of every workgroup divided between kv_nsplit workgroups; each writes a normalised partial (out, lse) to
+   * `workspace` and a second, streaming kernel combines the partials into the call's outputs (plain or accumulate mode
+   * alike).  workspace: rfa_fwd_workspace_bytes() bytes, or NULL (= never split).  kv_nsplit: 0 = chosen from the
+   * shapes, 1 = off, 2..8 forced (tests).  total_q: varlen only, number of packed q rows addressed (sizes the
+   * workspace).  Eligible: head dim 128 or 64 exactly, no window, no dropout. */
+  void *workspace;
+  int32_t kv_nsplit;
+  int64_t total_q;
 } rfa_fwd_args;
 
 enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_4x64 = 2 };
@@ -265,6 +276,9 @@ const char *rfa_build_id(void);
 const char *rfa_strerror(int status);
 
 int rfa_fwd(const rfa_fwd_args *args, void *stream);
+/* bytes of rfa_fwd_args.workspace the call can use (0: the call is never split); *nsplit (may be NULL) = the number of
+ * key-range shares the call runs with when given that workspace.  Pure function of the arguments. */
+int64_t rfa_fwd_workspace_bytes(const rfa_fwd_args *args, int32_t *nsplit);
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
 /* the launch plan of a call: *form = RFA_DKDV_128 / RFA_DKDV_256, *nsplit >= 1, *five_gemm = 1 when the call

@@ -89,6 +89,38 @@ const char* rfa_strerror(int status) {
   }
 }
 
+// Split-KV plan of a forward call: shares of the key tiles per workgroup (1 = no split).  Grids of the 128-row form that
+// leave most of the chip's 512 workgroup slots (two 4-wave workgroups per CU) empty while every workgroup has a long
+// chain of key tiles (>= 64: about 1 us each, walked one after the other) are split until the slots are filled, each
+// share keeping at least 32 tiles (measured: 16-tile shares lose to the combine pass — S = 2048 self-attention with 16
+// heads 0.042 -> 0.044 ms — while a llama3 head group at 2048 rows against 16384 gathered keys gains 14 %).
+static int fwd_kv_nsplit(const rfa_fwd_args* a) {
+  const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
+  if ((a->D != kHeadDim && a->D != kHeadDim / 2) || win || a->dropout_p > 0.f) return 1;
+  if (a->fwd_form != RFA_FWD_AUTO || a->kv_nsplit == 1 || a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return 1;
+  if (a->kv_nsplit > 1) return a->kv_nsplit > 8 ? 8 : a->kv_nsplit;
+  const int64_t wgs128 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + 127) / 128);
+  const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
+  if (wgs128 >= 384 || tiles < 64) return 1;
+  int ns = 1;
+  while (ns < 8 && wgs128 * (ns + 1) <= 640 && tiles / (ns + 1) >= 32) ++ns;
+  return ns;
+}
+static int64_t fwd_rows_total(const rfa_fwd_args* a) {
+  if (a->cu_seqlens_q != nullptr) return a->total_q > 0 ? a->total_q : 0;
+  return (int64_t)a->B * a->Sq;
+}
+
+int64_t rfa_fwd_workspace_bytes(const rfa_fwd_args* a, int32_t* nsplit) {
+  if (nsplit) *nsplit = 1;
+  if (!a || check_common(a->dtype, a->H, a->Hk, a->D, a->B)) return 0;
+  const int ns = fwd_kv_nsplit(a);
+  const int64_t rows = fwd_rows_total(a);
+  if (ns <= 1 || rows <= 0) return 0;
+  if (nsplit) *nsplit = ns;
+  return (int64_t)ns * rows * a->H * ((int64_t)a->D + 1) * 4;      // fp32 partial outs + partial lse
+}
+
 int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   if (!a) return RFA_ERR_NULL;
   int rc = check_common(a->dtype, a->H, a->Hk, a->D, a->B);
@@ -139,6 +171,35 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
         a->fwd_form == RFA_FWD_AUTO)                        // (RFA_FWD_8x32 by name: always the 256-row form)
       rows = 128;
   }
+  // split-KV (needs the caller's workspace): the 128-row form with the key tiles of a workgroup shared by kv_nsplit
+  const int ns = (a->workspace != nullptr && fwd_rows_total(a) > 0) ? fwd_kv_nsplit(a) : 1;
+  if (a->kv_nsplit < 0) return RFA_ERR_ARGS;
+  CombineParams cb{};
+  if (ns > 1) {
+    if (!aligned16(a->workspace)) return RFA_ERR_ALIGN;
+    rows = 128;
+    const int64_t rt = fwd_rows_total(a);
+    // partial layout: out (ns, rows_total, H, D) fp32, lse (ns, [B,] H, rows) fp32 behind it — addressed by the kernel
+    // through the accumulate-mode fields (the call's own accumulators, if any, are the combine kernel's business)
+    p.kv_nsplit = ns;
+    p.part_out = (float*)a->workspace;
+    p.part_lse = p.part_out + (int64_t)ns * rt * a->H * a->D;
+    p.part_out_split = rt * a->H * a->D;
+    p.part_lse_split = rt * a->H;
+    p.out_acc_st = Strides{a->cu_seqlens_q ? 0 : (int64_t)a->Sq * a->H * a->D, (int64_t)a->H * a->D, (int64_t)a->D};
+    p.lse_acc_batch = a->cu_seqlens_q ? 0 : (int64_t)a->H * a->Sq;
+    p.lse_acc_head = a->cu_seqlens_q ? rt : (int64_t)a->Sq;
+    cb.part_out = p.part_out; cb.part_lse = p.part_lse; cb.part_st = p.out_acc_st;
+    cb.part_lse_batch = p.lse_acc_batch; cb.part_lse_head = p.lse_acc_head;
+    cb.part_out_split = p.part_out_split; cb.part_lse_split = p.part_lse_split;
+    cb.nsplit = ns;
+    cb.out = a->out; cb.lse = a->lse; cb.out_acc = a->out_acc; cb.lse_acc = a->lse_acc;
+    cb.out_st = cv(a->out_st); cb.out_acc_st = cv(a->out_acc_st);
+    cb.lse_batch = a->lse_batch; cb.lse_head = a->lse_head;
+    cb.lse_acc_batch = a->lse_acc_batch; cb.lse_acc_head = a->lse_acc_head;
+    cb.cu_q = a->cu_seqlens_q;
+    cb.B = a->B; cb.H = a->H; cb.D = a->D; cb.Sq = a->Sq; cb.q_half = a->q_half; cb.acc_init = a->acc_init ? 1 : 0;
+  }
   p.qrows = rows;
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
   if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x64) return RFA_ERR_ARGS;
@@ -148,7 +209,9 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
 #else
   if (fwd_use_4x64(a)) return RFA_ERR_ARGS;             // the experiment is not in this build
 #endif
-  return launch_status(launch_fwd(p, a->dtype, (hipStream_t)stream));
+  if (int rc2 = launch_fwd(p, a->dtype, (hipStream_t)stream)) return launch_status(rc2);
+  if (ns > 1 && launch_combine(cb, a->dtype, (hipStream_t)stream)) return RFA_ERR_LAUNCH;
+  return RFA_OK;
 }
 
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args* a, void* stream) {

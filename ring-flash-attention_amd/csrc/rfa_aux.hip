@@ -222,6 +222,101 @@ int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream) {
   return ok();
 }
 
+// ------------------------------------------------------------------------------------
+// combine the partial (out, lse) pairs of a split-KV forward launch (rfa_fwd.hip: kv_nsplit):
+//     lse = logsumexp_s lse_s,   out = sum_s exp(lse_s - lse) out_s           (out_s normalised, lse_s = -inf: no key)
+// and deliver the result like the forward's own epilogue would have: plain (out io dtype, lse; +inf for rows without a
+// key) or merged into the fp32 (out_acc, lse_acc) pair with the same formula as the fused epilogue (acc_init: overwrite).
+// 16 lanes per (row, head), 8 columns per lane and pass.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void combine_kernel(const CombineParams p) {
+  const int b = blockIdx.y;
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  const int row = (int)(item / p.H);
+  const int h = (int)(item % p.H);
+  if (row >= qs.len) return;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t arow = qs.row0 + row;
+  const float* lp0 = p.part_lse + qbatch * p.part_lse_batch + (int64_t)h * p.part_lse_head + arow;
+  float mx = -INFINITY;
+  for (int s = 0; s < p.nsplit; ++s) mx = fmaxf(mx, lp0[(int64_t)s * p.part_lse_split]);
+  const bool has = mx > -INFINITY;
+  float den = 0.f;
+  for (int s = 0; s < p.nsplit; ++s) den += has ? __expf(lp0[(int64_t)s * p.part_lse_split] - mx) : 0.f;
+  const float blse = has ? mx + __logf(den) : -INFINITY;
+  // weights of the combined block inside the caller's accumulators (plain mode: the block IS the result)
+  float wo = 0.f, wb = 1.f, lnew = blse;
+  float* la = nullptr;
+  if (p.out_acc != nullptr) {
+    la = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + arow;
+    if (!p.acc_init) {
+      const float lold = *la;
+      const float m2 = fmaxf(lold, blse);
+      if (m2 > -INFINITY) {
+        const float eo = __expf(lold - m2), eb = __expf(blse - m2);
+        wo = eo / (eo + eb);
+        wb = eb / (eo + eb);
+        lnew = m2 + __logf(eo + eb);
+      } else {
+        wo = 1.f; wb = 0.f; lnew = lold;
+      }
+    }
+  }
+  const float* pp = p.part_out + qbatch * p.part_st.batch + arow * p.part_st.row + (int64_t)h * p.part_st.head;
+  for (int d = sub * 8; d < p.D; d += 128) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+      const float ls = lp0[(int64_t)s * p.part_lse_split];
+      const float w = has && ls > -INFINITY ? __expf(ls - mx) / den : 0.f;
+      const f32x4 x0 = *(const f32x4*)(pp + (int64_t)s * p.part_out_split + d);
+      const f32x4 x1 = *(const f32x4*)(pp + (int64_t)s * p.part_out_split + d + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[e] += w * x0[e]; acc[4 + e] += w * x1[e]; }
+    }
+    if (p.out_acc != nullptr) {
+      float* ap = p.out_acc + qbatch * p.out_acc_st.batch + arow * p.out_acc_st.row + (int64_t)h * p.out_acc_st.head + d;
+      f32x4 y0, y1;
+      if (p.acc_init) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = acc[e]; y1[e] = acc[4 + e]; }
+      } else {
+        y0 = *(f32x4*)ap;
+        y1 = *(f32x4*)(ap + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y0[e] = y0[e] * wo + acc[e] * wb; y1[e] = y1[e] * wo + acc[4 + e] * wb; }
+      }
+      *(f32x4*)ap = y0;
+      *(f32x4*)(ap + 4) = y1;
+    } else {
+      typedef float f32x8 __attribute__((ext_vector_type(8)));
+      f32x8 x;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = acc[e];
+      T* op = (T*)p.out + qbatch * p.out_st.batch + arow * p.out_st.row + (int64_t)h * p.out_st.head + d;
+      *(vec8<T>*)op = __builtin_convertvector(x, vec8<T>);
+    }
+  }
+  if (sub == 0) {
+    if (p.out_acc != nullptr) *la = lnew;
+    else p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + arow] = has ? blse : INFINITY;
+  }
+}
+
+int launch_combine(const CombineParams& p, int dtype, hipStream_t stream) {
+  const int rows = p.q_half ? (p.Sq + 1) / 2 : p.Sq;
+  const int64_t items = (int64_t)rows * p.H;
+  if (items <= 0 || p.B <= 0) return 0;
+  dim3 grid((unsigned)((items + 15) / 16), (unsigned)p.B);
+  if (dtype == 0) hipLaunchKernelGGL(combine_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(combine_kernel<f16_t>, grid, dim3(256), 0, stream, p);
+  return ok();
+}
+
 int launch_merge(const MergeParams& p, int dtype, hipStream_t stream) {
   const int64_t items = (int64_t)p.S * p.H;
   if (items <= 0 || p.B <= 0) return 0;

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   idx /= p.Hk;
   const int gq = idx % G;
   idx /= G;
+  const int nsplit = p.kv_nsplit > 1 ? p.kv_nsplit : 1;      // split-KV launch: which share of the key tiles
+  const int split = idx % nsplit;
+  idx /= nsplit;
   const int qblk = p.nqblk - 1 - (idx % p.nqblk);   // heavy (late) causal blocks first
   const int b = idx / p.nqblk;
   const int h = hk * G + gq;
@@ -132,10 +135,17 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   const int wr = kWin ? p.wr : 0, wl = kWin ? p.wl : 0;
   int kmax = lk;
   if (hi && qend + off + wr < kmax) kmax = qend + off + wr;
-  const int ntiles = kmax > 0 ? (kmax + kFwdKV - 1) / kFwdKV : 0;
+  int ntiles = kmax > 0 ? (kmax + kFwdKV - 1) / kFwdKV : 0;
   int kmin = lo ? qwg0 + off - wl : 0;
   kmin = kmin > 0 ? kmin : 0;
-  const int jt0 = (kmin / kFwdKV) / kFwdStages * kFwdStages;   // first tile (aligned to the LDS ring: stage = j % stages)
+  int jt0 = (kmin / kFwdKV) / kFwdStages * kFwdStages;   // first tile (aligned to the LDS ring: stage = j % stages)
+  if (nsplit > 1) {
+    // this workgroup's contiguous share of the tiles [jt0, ntiles), a multiple of the ring depth long (stage = j % stages)
+    int chunk = (ntiles - jt0 + nsplit - 1) / nsplit;
+    chunk = (chunk + kFwdStages - 1) / kFwdStages * kFwdStages;
+    jt0 += split * chunk;
+    ntiles = jt0 + chunk < ntiles ? jt0 + chunk : ntiles;          // (an empty share: jt0 >= ntiles -> no tile, l = 0)
+  }
 
   // ---- K/V tile staging.  Raw buffer loads: the per-thread byte offsets are fixed for the whole kernel,
   // the tile advance lives in the scalar descriptor, rows past the end of the sequence read as zero.
@@ -426,15 +436,18 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   const float blse = has ? m * p.scale + __logf(l) : INFINITY;   // natural log
   const int64_t orow = qs.row0 + qrow;
 
-  if (p.out_acc == nullptr) {
+  if (p.out_acc == nullptr && nsplit == 1) {
     T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
     store_rows16<T, kFullD, kNB>(ob, o, inv, g, p.D, true);
     if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
   } else {
-    float* ab = p.out_acc + qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row +
-                (int64_t)h * p.out_acc_st.head;
-    float* lp = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
-    if (p.acc_init) {
+    // split-KV launch: the normalised partial of this split goes to its slot of the workspace (laid out like
+    // out_acc / lse_acc, rfa_api.cpp), overwriting; combine_kernel merges the slots into the call's outputs
+    float* ab = (nsplit > 1 ? p.part_out + (int64_t)split * p.part_out_split : p.out_acc) +
+                qbatch * p.out_acc_st.batch + orow * p.out_acc_st.row + (int64_t)h * p.out_acc_st.head;
+    float* lp = (nsplit > 1 ? p.part_lse + (int64_t)split * p.part_lse_split : p.lse_acc) +
+                qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
+    if (p.acc_init || nsplit > 1) {
 #pragma unroll
       for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
@@ -479,7 +492,7 @@ template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false, int kW
 static int launch_fwd_w(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
   if (int rc = opt_in_dynamic_lds((const void*)fwd_kernel<T, kD, kFullD, kWin, kDrop, kW>, fwd_smem<kD>(), attr_done)) return rc;
-  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
+  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B * (p.kv_nsplit > 1 ? p.kv_nsplit : 1);
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL((fwd_kernel<T, kD, kFullD, kWin, kDrop, kW>), dim3((unsigned)nblocks), dim3(kW * 64), fwd_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;

@@ -47,6 +47,14 @@ struct FwdParams {
                        // (causal is folded in by the API layer: wr = 0)
   int nqblk;
   int qrows;           // query rows per workgroup the launch was sized for: 256 (8 waves) or 128 (4 waves, small grids)
+  // split-KV launches (short query ranges against long key ranges on under-filled grids): the key tiles of a workgroup's
+  // range are divided between kv_nsplit workgroups; split s writes a NORMALISED partial (out fp32, lse; -inf = no key)
+  // to part_out + s * part_out_split / part_lse + s * part_lse_split (laid out like out_acc / lse_acc), and
+  // combine_kernel (rfa_aux.hip) merges the splits into the call's real outputs
+  int kv_nsplit;
+  float* part_out;
+  float* part_lse;
+  int64_t part_out_split, part_lse_split;
   float scale;
   // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
   // the offsets that turn local (head, query position, key position) into global ones
@@ -113,6 +121,23 @@ struct ReduceParams {
   int B, Hk, G, D, Sk, k_half, acc_init;
   int src_f32;
   int64_t g_stride;    // 0: member g of head hk is source head hk*G+g; else: head hk, g_stride elements further per g
+};
+
+// combine the kv_nsplit partial (out, lse) pairs of a split-KV forward launch into the call's outputs
+struct CombineParams {
+  const float* part_out;    // (nsplit, ...) laid out like out_acc: strides part_st, split stride part_out_split
+  const float* part_lse;
+  Strides part_st;
+  int64_t part_lse_batch, part_lse_head, part_out_split, part_lse_split;
+  int nsplit;
+  void* out;                // io dtype (plain mode) or nullptr
+  float* lse;
+  float* out_acc;           // fp32 accumulate mode or nullptr
+  float* lse_acc;
+  Strides out_st, out_acc_st;
+  int64_t lse_batch, lse_head, lse_acc_batch, lse_acc_head;
+  const int32_t* cu_q;
+  int B, H, D, Sq, q_half, acc_init;
 };
 
 struct MergeParams {
@@ -185,6 +210,7 @@ int bwd_dq_rows_per_block();
 int bwd_dkdv_keys_per_block(bool wide);
 int launch_reduce(const ReduceParams& p, int dtype, hipStream_t stream);
 int launch_merge(const MergeParams& p, int dtype, hipStream_t stream);
+int launch_combine(const CombineParams& p, int dtype, hipStream_t stream);
 int launch_cast(void* dst, const float* src, int64_t n, int dtype, hipStream_t stream);
 int launch_lse_relayout(float* dst, const float* src, const int32_t* cu, int B, int H,
                         int max_seqlen, int64_t packed_head_stride, int64_t packed_row_stride,

@@ -44,6 +44,7 @@ class FwdArgs(C.Structure):
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
         ("q_pos_offset", C.c_int64), ("k_pos_offset", C.c_int64), ("head_offset", C.c_int32),
         ("fwd_form", C.c_int32),
+        ("workspace", C.c_void_p), ("kv_nsplit", C.c_int32), ("total_q", C.c_int64),
     ]
 
 
@@ -121,6 +122,7 @@ SYMBOLS = {
     "rfa_build_id": (C.c_char_p, []),
     "rfa_strerror": (C.c_char_p, [C.c_int]),
     "rfa_fwd": (C.c_int, [C.POINTER(FwdArgs), C.c_void_p]),
+    "rfa_fwd_workspace_bytes": (C.c_int64, [C.POINTER(FwdArgs), C.POINTER(C.c_int32)]),
     "rfa_bwd_preprocess": (C.c_int, [C.POINTER(BwdPreArgs), C.c_void_p]),
     "rfa_bwd_workspace_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),
     "rfa_bwd_ds_scratch_bytes": (C.c_int64, [C.POINTER(BwdArgs)]),

@@ -104,6 +104,7 @@ class HipBackend:
             a.H, a.D = q.shape[1], q.shape[2]
             a.Hk = k.shape[1]
             a.Sq, a.Sk = int(max_seqlen_q), int(max_seqlen_k)
+            a.total_q = q.shape[0]
         else:
             a.B, a.Sq, a.H, a.D = q.shape
             a.Sk, a.Hk = k.shape[1], k.shape[2]
@@ -115,6 +116,14 @@ class HipBackend:
         a.dtype = self._dtype(q)
         _set_dropout(a, dropout)
         a.fwd_form = _fwd_form()
+        a.kv_nsplit = config.get().fwd_kv_nsplit
+        # split-KV launches (few query rows against many keys on an under-filled grid: include/rfa.h) need a small
+        # workspace for the partial (out, lse) pairs: a few tens of MB, only for the calls that split
+        ws = None
+        nbytes = self.lib.rfa_fwd_workspace_bytes(C.byref(a), None)
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            a.workspace = ws.data_ptr()
         _C.check(self.lib.rfa_fwd(C.byref(a), _stream(q)), "rfa_fwd")
 
     # ------------------------------------------------------------------ backward

@@ -24,6 +24,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | ds_spill_max_frac         | RFA_DS_SPILL_MAX_FRAC           | 0.5     | ... and never more than this fraction of the memory free when it is first taken |
 | fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 / 4x64 |
 | dkdv_wide, dkdv_nsplit    | RFA_DKDV_WIDE, RFA_DKDV_NSPLIT  | unset   | dK/dV launch plan overrides (tuning / tests) |
+| fwd_kv_nsplit             | RFA_FWD_KV_NSPLIT               | 0       | split-KV forward launches: 0 chosen from the shapes, 1 off, 2..8 forced (tuning / tests) |
 | tuning_log                | RFA_TUNING_LOG                  | 0       | print autotune decisions on rank 0 |
 | force_steps               | RFA_TEST_FORCE_STEPS            | 0       | TEST HOOK: keep the multi-step path on a one-rank group (RCCL calls on a one-GPU box) |
 """
@@ -87,6 +88,7 @@ class Config:
     fwd_form: str = "auto"
     dkdv_wide: int = -1          # -1 unset, 0 the 128-key form, 1 the 256-key form
     dkdv_nsplit: int = 0         # 0 unset
+    fwd_kv_nsplit: int = 0       # 0: chosen from the shapes; 1: never split; 2..8 forced
     tuning_log: bool = False
     force_steps: bool = False
 
@@ -132,6 +134,8 @@ class Config:
             c.dkdv_wide = 1 if _bool("RFA_DKDV_WIDE", r) else 0
         if (r := get("RFA_DKDV_NSPLIT")) is not None:
             c.dkdv_nsplit = _int("RFA_DKDV_NSPLIT", r)
+        if (r := get("RFA_FWD_KV_NSPLIT")) is not None:
+            c.fwd_kv_nsplit = _int("RFA_FWD_KV_NSPLIT", r)
         if (r := get("RFA_TUNING_LOG")) is not None:
             c.tuning_log = _bool("RFA_TUNING_LOG", r)
         if (r := get("RFA_TEST_FORCE_STEPS")) is not None:

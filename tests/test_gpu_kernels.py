@@ -751,6 +751,7 @@ def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq
 
     set_backend(None)
     be, dev = get_backend(), _dev()
+    monkeypatch.setenv("RFA_FWD_KV_NSPLIT", "1")      # (split-KV launches regroup the sum over the keys: tested on their own)
     g = torch.Generator().manual_seed(Sq + Sk)
     q = torch.randn(B, Sq, H, D, generator=g).to(dtype)
     k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype)
@@ -776,6 +777,85 @@ def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal,nsplit", [
+    (1, 256, 4096, 4, 2, 128, True, "0"),        # the regime it exists for: few rows, 64 key tiles -> 2 shares (the library's choice)
+    (2, 200, 3000, 2, 2, 128, True, "3"),        # ragged tails, bottom-right alignment, odd tile count, forced 3 shares
+    (1, 300, 1000, 2, 1, 64, False, "8"),        # head dim 64; more shares than tile pairs: empty shares
+    (1, 700, 520, 2, 2, 128, True, "2"),         # more queries than keys: rows without any key (lse = +inf)
+])
+def test_fwd_split_kv_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, D, causal, nsplit):
+    """ABI 5 split-KV forward launches: the key tiles of a workgroup divided between several workgroups, normalised
+    partials in a workspace, a combine pass — against the oracle and against the unsplit launch, plain outputs and the
+    fused merge into fp32 accumulators (overwrite and +=)"""
+    import ctypes as C
+
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn import _C
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    g = torch.Generator().manual_seed(Sq * 7 + Sk)
+    q = torch.randn(B, Sq, H, D, generator=g).to(BF)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(BF)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(BF)
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, D ** -0.5, causal)
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    res = {}
+    for mode in (nsplit, "1"):
+        monkeypatch.setenv("RFA_FWD_KV_NSPLIT", mode)
+        out = torch.empty(B, Sq, H, D, dtype=BF, device=dev)
+        lse = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+        be.fwd(qd, kd, vd, softmax_scale=D ** -0.5, causal=causal, out=out, lse=lse)
+        # accumulate mode: first half of the keys overwrites, second half merges in (non-causal halves: the ring steps' use)
+        acc = torch.full((B, Sq, H, D), 7.0, dtype=torch.float32, device=dev)
+        lacc = torch.full((B, H, Sq), 3.0, dtype=torch.float32, device=dev)
+        half = Sk // 2
+        be.fwd(qd, kd[:, :half], vd[:, :half], softmax_scale=D ** -0.5, causal=False, out_acc=acc, lse_acc=lacc, acc_init=True)
+        be.fwd(qd, kd[:, half:], vd[:, half:], softmax_scale=D ** -0.5, causal=False, out_acc=acc, lse_acc=lacc)
+        res[mode] = (out, lse, acc, lacc)
+        _check(f"split{mode}.out", out, ro, 0, kind="out")
+        _check(f"split{mode}.lse", lse, rl, 0, kind="lse")
+    # the library's plan for the first case
+    if nsplit == "0":
+        a = _C.FwdArgs()
+        a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype, a.causal = B, Sq, Sk, H, Hk, D, 0, 1
+        n = C.c_int32()
+        nbytes = be.lib.rfa_fwd_workspace_bytes(C.byref(a), C.byref(n))
+        assert n.value == 2 and nbytes == 2 * B * Sq * H * (D + 1) * 4
+    ra, rla, _, _ = O._flash_attn_forward(q, k, v, 0.0, D ** -0.5, False)
+    _check("split.acc.out", res[nsplit][2], ra.float(), 0, kind="out")
+    _check("split.acc.lse", res[nsplit][3], rla, 0, kind="lse")
+    _check("split vs unsplit out", res[nsplit][0], res["1"][0].float(), 0, kind="out")
+    _check("split vs unsplit acc", res[nsplit][2], res["1"][2], 0, kind="out")
+    assert (res[nsplit][1] - res["1"][1])[torch.isfinite(res["1"][1])].abs().max().item() < 1e-5
+
+
+def test_fwd_split_kv_packed_sequences(single_rank_group, monkeypatch):
+    """split-KV over packed sequences of very different lengths (shares that are empty for the short sequences) through the
+    public varlen API, single-rank; and the llama3 path whose long gathered key ranges are what the form is for"""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(99)
+    cu = [0, 40, 2100, 2164, 4200]
+    T = cu[-1]
+    q = torch.randn(T, 4, 128, generator=g).to(BF)
+    k = torch.randn(T, 2, 128, generator=g).to(BF)
+    v = torch.randn(T, 2, 128, generator=g).to(BF)
+    do = torch.randn(T, 4, 128, generator=g).to(BF)
+    cut = torch.tensor(cu, dtype=torch.int32)
+    ro, rl, rdq, rdk, rdv = _oracle_varlen(q, k, v, do, cut, cut, True)
+    for mode in ("4", "1"):
+        monkeypatch.setenv("RFA_FWD_KV_NSPLIT", mode)
+        qd, kd, vd = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        out, lse, _ = R.ring_flash_attn_varlen_func(qd, kd, vd, cut.to(dev), 2060, causal=True, return_attn_probs=True)
+        out.backward(do.to(dev))
+        _check(f"varlen.split{mode}.out", out, ro, 0, kind="out")
+        _check(f"varlen.split{mode}.lse", lse, rl, 0, kind="lse")
+        _grads_ok(f"varlen.split{mode}", (qd.grad, kd.grad, vd.grad), (rdq, rdk, rdv))
+
+
 def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
     """packed sequences, half-sequence selectors and the fused fp32 merge epilogue: the zigzag varlen schedule forced
     onto its multi-step path (RFA_TEST_FORCE_STEPS) with the library's choice of the forward form (128 rows on this
@@ -784,6 +864,7 @@ def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
 
     dev = _dev()
     monkeypatch.setenv("RFA_TEST_FORCE_STEPS", "1")
+    monkeypatch.setenv("RFA_FWD_KV_NSPLIT", "1")
     g = torch.Generator().manual_seed(64)
     cu = torch.tensor([0, 128, 1248, 2240], dtype=torch.int32, device=dev)
     q = torch.randn(2240, 4, 128, generator=g).to(BF).to(dev)
