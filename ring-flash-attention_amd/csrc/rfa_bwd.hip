@@ -619,6 +619,8 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       tq[kv][hh] = lds_addr(smem) + par * 32 * kRowBytes + tr_off_d<kD>(lane, 0, 16 * kv + 8 * hh + 4 * g);
       pin_vgpr(tq[kv][hh]);
     }
+  int mask_g4 = 4 * g, mask_kg = krow - 4 * g;        // mask of (query sq + 4 g, key krow): see the exp / mask section
+  pin_vgpr(mask_g4); pin_vgpr(mask_kg);
   int sa = lds_addr(smem) + kOffStat + (32 * par + 4 * g) * 4;                       // row statistics (stage toggled)
   int avp = av;
   pin_vgpr(aq); pin_vgpr(avp); pin_vgpr(sa); pin_vgpr(wq); pin_vgpr(ws);
@@ -739,8 +741,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       if (RFA_KV_X_VALU && need_mask) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int q = qs0 + crow(r, g);
-          const bool ok = (q < lq) && (!hi || krow <= q + off + wr) && (!lo || krow >= q + off - wl);
+          // query row q = qs0 + crow(r, g) = sq + 4 g with sq wave-uniform: every comparison is (a loop-invariant lane
+          // value) against (a scalar) — no per-element vector arithmetic, and nothing for the compiler to hoist into
+          // 16 registers that stay live across the whole tile loop (255 -> 240 registers in the headline instance)
+          const int sq = qs0 + crow(r, 0);
+          const bool ok = (mask_g4 < lq - sq) & (!hi | (mask_kg <= sq + off + wr)) & (!lo | (mask_kg >= sq + off - wl));
           s[r] = ok ? s[r] : 0.f;
         }
       }
