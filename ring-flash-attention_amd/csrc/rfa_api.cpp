@@ -167,9 +167,10 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   {
     const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
     const int64_t wgs8 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + rows - 1) / rows);
-    if ((a->D == kHeadDim || a->D == kHeadDim / 2) && !win && !(a->dropout_p > 0.f) && wgs8 < 384 &&
-        a->fwd_form == RFA_FWD_AUTO)                        // (RFA_FWD_8x32 by name: always the 256-row form)
-      rows = 128;
+    if ((a->D == kHeadDim || a->D == kHeadDim / 2) && !win && !(a->dropout_p > 0.f) &&
+        (((wgs8 < 384 || eff_len(a->Sq, a->q_half) <= 1024) && a->fwd_form == RFA_FWD_AUTO) ||
+         a->fwd_form == RFA_FWD_4x32))      // (RFA_FWD_8x32 by name: always the 256-row form, RFA_FWD_4x32: the 128-row form
+      rows = 128;                           //  wherever it exists; sequences <= 1024: +6 % at 1024, +13 % at 512, -2 % from 2048 on)
   }
   // split-KV (needs the caller's workspace): the 128-row form with the key tiles of a workgroup shared by kv_nsplit
   const int ns = (a->workspace != nullptr && fwd_rows_total(a) > 0) ? fwd_kv_nsplit(a) : 1;
@@ -202,7 +203,7 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   }
   p.qrows = rows;
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
-  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x64) return RFA_ERR_ARGS;
+  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x32) return RFA_ERR_ARGS;
   if (a->D > kHeadDim) return launch_status(launch_fwd_big(p, a->dtype, (hipStream_t)stream));
 #if RFA_WITH_FWD64
   if (fwd_use_4x64(a)) return launch_status(launch_fwd64(p, a->dtype, (hipStream_t)stream));
