@@ -283,11 +283,16 @@ static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
     kblocks = eff < kblocks ? eff : kblocks;
   }
   const int64_t wgs = kblocks * hk_launch;
+  // Sharing a key block's query range between workgroups (fp32 partials + reduce_kernel) pays for the causal imbalance of
+  // LONG query ranges only: measured (profiles/r04_dkdv_plans_short_sequences.txt, B x S = 8192, Hk 8) S 1024: 0.374 ms
+  // with two shares, 0.341 with the 128-key form, 0.321 with unshared 256-key workgroups; S 2048: 0.591 / 0.572 / 0.585;
+  // S 4096: 0.872 / 0.862 / 1.060.  So: shares of >= 2048 rows; sequences <= 1024 take the 256-key form unshared
+  // whenever that still gives 160 workgroups; otherwise the 256-key form needs 320.
   int ns = 1;
-  while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 512) ++ns;
+  while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 2048) ++ns;
   const bool forced = a->dkdv_form == RFA_DKDV_256;
   if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
-  if (wgs * ns < 320 && !forced && a->dkdv_nsplit <= 0) return pl;
+  if (!forced && a->dkdv_nsplit <= 0 && (sq <= 1024 ? wgs < 160 : wgs * ns < 320)) return pl;
   pl.wide = 1;
   pl.nsplit = ns;
   return pl;

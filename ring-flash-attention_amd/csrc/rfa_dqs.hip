@@ -39,15 +39,22 @@
 
 namespace rfa {
 
-constexpr int kDsWaves = 8;
-constexpr int kDsThreads = kDsWaves * 64;
-constexpr int kDsRows = kDsWaves * 32;                 // query rows per workgroup
 constexpr int kDsKV = 64;                              // keys per tile = 2 dS blocks per wave
-constexpr int kDsStages = 3;
 constexpr int kDsKBytes = kDsKV * kRowBytes;           // 16 KiB K tile
 constexpr int kDsWaveBytes = 2 * kDsBlockBytes;        // 4 KiB of dS per wave and tile
-constexpr int kDsSBytes = kDsWaves * kDsWaveBytes;     // 32 KiB
-constexpr int kDsSmem = kDsStages * (kDsKBytes + kDsSBytes);   // 144 KiB
+// Two forms: 8 waves = 256 query rows per workgroup through a 3-stage ring (144 KiB: the headline's grid of 1024
+// workgroups), and 4 waves = 128 rows through a 4-stage ring (128 KiB, three tiles in flight) for grids that would leave
+// half of the CUs without a workgroup — the stream is HBM-bound, what counts is the bytes in flight over the whole chip
+// (a llama3 head group at 2048 tokens per rank: 128 workgroups of 256 rows -> 256 of 128 rows)
+template <int kW> struct DsGeo {
+  static constexpr int kThreads = kW * 64;
+  static constexpr int kRows = kW * 32;                // query rows per workgroup
+  static constexpr int kStages = kW == 8 ? 3 : 4;
+  static constexpr int kSBytes = kW * kDsWaveBytes;    // 32 / 16 KiB of dS per tile
+  static constexpr int kSmem = kStages * (kDsKBytes + kSBytes);
+  static constexpr int kKPieces = 16 / kW;             // 1 KiB K pieces per wave and tile
+  static constexpr int kDmaPerTile = kKPieces + 4;     // DMA instructions per wave and tile
+};
 
 __device__ __forceinline__ void dma_load128_stream(dma_rsrc_t r, int lds_wave_base, int voffset) {
 #if RFA_DQS_NT
@@ -60,8 +67,10 @@ __device__ __forceinline__ void dma_load128_stream(dma_rsrc_t r, int lds_wave_ba
 #endif
 }
 
-template <typename T>
-__global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p) {
+template <typename T, int kW>
+__global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const BwdParams p) {
+  typedef DsGeo<kW> Geo;
+  constexpr int kDsRows = Geo::kRows, kDsStages = Geo::kStages, kDsSBytes = Geo::kSBytes;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   // LDS map: K stages at [0, 3 x 16K), dS stages behind them ([stage][wave][4K])
@@ -117,10 +126,10 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
 
   // K tile DMA: as in the forward kernel (lane L of the piece for row group c = wave + 8 i lands in row
   // 4c + L/16, physical chunk L%16 and fetches the logical chunk the swizzle puts there)
-  int voff_k[2];
+  int voff_k[Geo::kKPieces];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 4 * (wave + 8 * i) + (lane >> 4);
+  for (int i = 0; i < Geo::kKPieces; ++i) {
+    const int row = 4 * (wave + kW * i) + (lane >> 4);
     const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
     voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
   }
@@ -132,8 +141,8 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
     const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
     const dma_rsrc_t rk = make_dma_rsrc(kbase + (int64_t)j * kDsKV * p.k_st.row, nk);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      dma_load128(rk, lds_addr(smem) + kStage * kDsKBytes + (wave + 8 * i) * 1024, voff_k[i]);
+    for (int i = 0; i < Geo::kKPieces; ++i)
+      dma_load128(rk, lds_addr(smem) + kStage * kDsKBytes + (wave + kW * i) * 1024, voff_k[i]);
     const int sdst = lds_addr(smem) + kOffS + kStage * kDsSBytes + wave * kDsWaveBytes;
 #pragma unroll
     for (int d = 0; d < 4; ++d)          // blocks kb = 2j, 2j+1 (past the run: descriptor range -> zeros)
@@ -171,11 +180,15 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   typedef std::integral_constant<int, 0> st0;
   typedef std::integral_constant<int, 1> st1;
   typedef std::integral_constant<int, 2> st2;
+  typedef std::integral_constant<int, 3> st3;
+  constexpr int kFly = (kDsStages - 2) * Geo::kDmaPerTile;   // DMA instructions that may stay in flight behind the tile awaited
   load_tile(0, st0{});
-  if (ntiles > 1) {
+  if (ntiles >= kDsStages - 1) {
     load_tile(1, st1{});
-    wait_vmem<6>();
+    if (kDsStages > 3) load_tile(2, st2{});
+    wait_vmem<kFly>();
   } else {
+    if (ntiles > 1) load_tile(1, st1{});
     wait_all_vmem();
   }
   __syncthreads();
@@ -184,9 +197,9 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
     constexpr int kStage = decltype(stage)::value;
     constexpr int kbo = kStage * kDsKBytes;
     constexpr int sbo = kStage * kDsSBytes;
-    typedef std::integral_constant<int, (kStage + 2) % kDsStages> fill_t;
-    const bool more = j + 2 < ntiles;
-    if (more) load_tile(j + 2, fill_t{});
+    typedef std::integral_constant<int, (kStage + kDsStages - 1) % kDsStages> fill_t;
+    const bool more = j + kDsStages - 1 < ntiles;
+    if (more) load_tile(j + kDsStages - 1, fill_t{});
     if (qw0 < lq) {
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
@@ -212,14 +225,15 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
         }
       }
     }
-    if (more) wait_vmem<6>();        // tile j+1 has landed; the 6 DMA instructions of tile j+2 may fly on
+    if (more) wait_vmem<kFly>();     // tile j+1 has landed; the DMA instructions of the tiles behind it may fly on
     else wait_all_vmem();
     __syncthreads();
   };
-  for (int j = 0; j < ntiles; j += 3) {
+  for (int j = 0; j < ntiles; j += kDsStages) {
     tile_step(j, st0{});
     if (j + 1 < ntiles) tile_step(j + 1, st1{});
     if (j + 2 < ntiles) tile_step(j + 2, st2{});
+    if (kDsStages > 3 && j + 3 < ntiles) tile_step(j + 3, st3{});
   }
 
   if (qrow >= lq) return;
@@ -248,14 +262,29 @@ __global__ __launch_bounds__(kDsThreads, 2) void dq_ds_kernel(const BwdParams p)
   }
 }
 
-template <typename T>
-static int launch_dq_ds_t(const BwdParams& p, hipStream_t stream) {
+template <typename T, int kW>
+static int launch_dq_ds_w(BwdParams p, hipStream_t stream) {
+  typedef DsGeo<kW> Geo;
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dq_ds_kernel<T>, kDsSmem, attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dq_ds_kernel<T, kW>, Geo::kSmem, attr_done)) return rc;
+  const int lq = p.q_half ? (p.Sq + 1) / 2 : p.Sq;       // (the longest (half) sequence: rfa_api.cpp eff_len)
+  p.nqblk = (lq + Geo::kRows - 1) / Geo::kRows;
   const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dq_ds_kernel<T>), dim3((unsigned)nblocks), dim3(kDsThreads), kDsSmem, stream, p);
+  hipLaunchKernelGGL((dq_ds_kernel<T, kW>), dim3((unsigned)nblocks), dim3(Geo::kThreads), Geo::kSmem, stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
+}
+
+template <typename T>
+static int launch_dq_ds_t(const BwdParams& p, hipStream_t stream) {
+  // 128-row workgroups when the 256-row grid would leave CUs without one (one workgroup per CU in both forms)
+  const int lq = p.q_half ? (p.Sq + 1) / 2 : p.Sq;
+  const int64_t wgs8 = (int64_t)((lq + 255) / 256) * p.H * p.B;
+#ifndef RFA_DQS_FORM
+#define RFA_DQS_FORM 0       // tuning: 8 / 4 = always that form
+#endif
+  const bool small = RFA_DQS_FORM == 4 || (RFA_DQS_FORM == 0 && wgs8 < 256);
+  return small ? launch_dq_ds_w<T, 4>(p, stream) : launch_dq_ds_w<T, 8>(p, stream);
 }
 
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream) {

@@ -271,7 +271,14 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 8192, 8192, 32, 8, form=_C.DKDV_128)) == 0
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == (_C.DKDV_256, 3)
     assert ws(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == 3 * unit32(1024, 2)
-    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 2)    # (split count still by shape)
+    assert plan(args(1, 4096, 4096, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 2)    # (split count still by shape)
+    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 1)    # (... shares of >= 2048 query rows)
+    # short sequences (profiles/r04_dkdv_plans_short_sequences.txt): <= 1024 the 256-key form unshared from 160 workgroups
+    # on; 2048 with 256 workgroups: the 128-key form; 4096: two shares
+    assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_256, 1)
+    assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_256, 1)
+    assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_128, 1)
+    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 2)
     # ... the process environment does not reach the library
     monkeypatch.setenv("RFA_DKDV_WIDE", "0")
     monkeypatch.setenv("RFA_DKDV_NSPLIT", "3")
