@@ -309,7 +309,7 @@ static bool bwd_needs_ws(const rfa_bwd_args* a) {
 }
 
 static bool bwd_spill_eligible(const rfa_bwd_args* a) {
-  return (a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && (a->D == kHeadDim || a->D == 2 * kHeadDim) &&
+  return (a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && a->D >= kHeadDim && a->D <= 2 * kHeadDim &&
          a->B > 0 && a->Sq > 0 && a->Sk > 0 && !(a->dropout_p > 0.f) &&
          !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
 }

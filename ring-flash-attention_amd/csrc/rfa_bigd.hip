@@ -19,6 +19,8 @@
 //     chunk) — the 5-GEMM form of rfa_bwd.hip; other wide dims recompute S and dP in dq_big_kernel.
 // These are coverage kernels, written for clarity: no hand-placed schedules beyond reading LDS operands ahead of their
 // MFMAs and issuing the next tile's DMA pieces in MFMA shadows.  Measured rates are in DESIGN.md §3.2.
+#include <type_traits>
+
 #include "rfa_common.hpp"
 #include "rfa_kernels.hpp"
 
@@ -27,8 +29,8 @@ namespace rfa {
 constexpr int kBgWaves = 4;
 constexpr int kBgThreads = kBgWaves * 64;
 constexpr int kBgRows = kBgWaves * 32;        // query rows (forward, dQ) / keys (dK/dV) per workgroup
-constexpr int kBgNK = 16;                     // 16-wide k-steps of a contraction over 256 columns
-constexpr int kBgNB = 8;                      // 32-wide column blocks of an accumulator row
+// (per kernel instance: kNK = 4 kQ 16-wide k-steps of a contraction, kNB = 2 kQ 32-wide column blocks of an accumulator
+//  row, kQ = the 64-column quarters of the 256-wide row that hold data: 3 for head dims <= 192, else 4)
 constexpr int kBgOob = 0x7ffffff0;            // byte offset past every descriptor range: the lane reads / DMAs zeros
 
 // Per-lane global byte offsets of the LDS-DMA pieces one wave issues for a wide tile of R rows.  Piece P (1 KiB =
@@ -69,6 +71,9 @@ __device__ __forceinline__ void big_dma_tile(dma_rsrc_t r, int lds_base, int wav
 #endif
 // measurement-only switches for dkdv_big_kernel (results are wrong when one is 0): the loop without its DMA pieces /
 // its per-tile wait + barrier / the exp-mask-multiply work / the LDS fragment reads
+#ifndef RFA_BG_FUSED_KV
+#define RFA_BG_FUSED_KV 0    // 1: head dims <= 192 compute dK and dV in ONE launch (see dkdv_big_kernel: spills with hipcc 7.2)
+#endif
 #ifndef RFA_BG_X_DMA
 #define RFA_BG_X_DMA 1
 #endif
@@ -115,8 +120,9 @@ constexpr int kBgChunkTile = kBgKV * 256;          // [64][128] chunk tile
 constexpr int kBgTile = 2 * kBgChunkTile;          // [64][256]
 constexpr int kBgFwdSmem = 4 * kBgTile;            // K[2] V[2]: 128 KiB
 
-template <typename T>
+template <typename T, int kQ>
 __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) {
+  constexpr int kNK = 4 * kQ, kNB = 2 * kQ;         // k-steps / column blocks that hold data (kQ quarters of 64 columns)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   const int tid = threadIdx.x;
@@ -151,9 +157,9 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
   const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
   const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
 
-  vec8<T> qf[kBgNK];
+  vec8<T> qf[kNK];
 #pragma unroll
-  for (int kk = 0; kk < kBgNK; ++kk) {
+  for (int kk = 0; kk < kNK; ++kk) {
     const int d0 = 16 * kk + 8 * g;
     qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
   }
@@ -217,9 +223,9 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
   const float c = p.scale * kLog2e;
   float m = -INFINITY;
   float lsum = 0.f;
-  f32x16 o[kBgNB];
+  f32x16 o[kNB];
 #pragma unroll
-  for (int i = 0; i < kBgNB; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
 
@@ -244,9 +250,12 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-      big_gemm<T, 2 * kBgNK, 1>(
-          [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + kbo + ((i >> 3) & 1) * kBgChunkTile + (i >> 4) * 32 * 256); },
-          [&](int i, vec8<T> a) { s[i >> 4] = mfma(a, qf[i & 15], s[i >> 4]); },
+      big_gemm<T, 2 * kNK, 1>(
+          [&](int i) {                                  // i = t * kNK + kk
+            const int t = i / kNK, kk = i % kNK;
+            return lds_read128<T>(lds_ptr(koff[kk & 7]) + kbo + (kk >> 3) * kBgChunkTile + t * 32 * 256);
+          },
+          [&](int i, vec8<T> a) { s[i / kNK] = mfma(a, qf[i % kNK], s[i / kNK]); },
           [&](int i) {                                  // the next tile's DMA pieces in the shadows of the first MFMAs
             if (i < kPieces && more) issue_piece(nxt, i);
           });
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
         m = mnew;
         lsum *= alpha;
 #pragma unroll
-        for (int i = 0; i < kBgNB; ++i)
+        for (int i = 0; i < kNB; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
@@ -312,12 +321,12 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
         vec8<T> pb[4];                                  // [t][ks2]
 #pragma unroll
         for (int x = 0; x < 4; ++x) pb[x] = pack8<T>(s[x >> 1], 8 * (x & 1));
-        big_gemm<T, 4 * kBgNB, 2>(
-            [&](int i) {                                // i = (t, ks2) * 8 + dblk: rows 32 t + 16 ks2 of the V tile
-              const int dblk = i & 7, cimm = vbo + (i >> 3) * 16 * 256 + (dblk >> 2) * kBgChunkTile;
+        big_gemm<T, 4 * kNB, 2>(
+            [&](int i) {                                // i = (t, ks2) * kNB + dblk: rows 32 t + 16 ks2 of the V tile
+              const int dblk = i % kNB, cimm = vbo + (i / kNB) * 16 * 256 + (dblk >> 2) * kBgChunkTile;
               return concat<T>(lds_read_tr<T>(lds_ptr(voff[dblk & 3][0]) + cimm), lds_read_tr<T>(lds_ptr(voff[dblk & 3][1]) + cimm));
             },
-            [&](int i, vec8<T> a) { o[i & 7] = mfma(a, pb[i >> 3], o[i & 7]); });
+            [&](int i, vec8<T> a) { o[i % kNB] = mfma(a, pb[i / kNB], o[i % kNB]); });
       }
     }
     wait_all_vmem();           // tile j+1 has landed
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
   const int64_t orow = qs.row0 + qrow;
   if (p.out_acc == nullptr) {
     T* ob = (T*)p.out + qbatch * p.out_st.batch + orow * p.out_st.row + (int64_t)h * p.out_st.head;
-    store_rows16<T, false, kBgNB>(ob, o, inv, g, p.D, true);
+    store_rows16<T, false, kNB>(ob, o, inv, g, p.D, true);
     if (g == 0) p.lse[qbatch * p.lse_batch + (int64_t)h * p.lse_head + orow] = blse;
   } else {
     // fused online merge into the caller's fp32 accumulators: the epilogue of rfa_fwd.hip
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
     float* lp = p.lse_acc + qbatch * p.lse_acc_batch + (int64_t)h * p.lse_acc_head + orow;
     if (p.acc_init) {
 #pragma unroll
-      for (int dblk = 0; dblk < kBgNB; ++dblk)
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -362,7 +371,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
       const float wb = eb / den * inv;
       const float lnew = mx + __logf(den);
 #pragma unroll
-      for (int dblk = 0; dblk < kBgNB; ++dblk)
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -381,8 +390,9 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
 // =====================================================================================
 // dQ (7-GEMM form: S and dP recomputed)
 // =====================================================================================
-template <typename T>
+template <typename T, int kQ>
 __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
+  constexpr int kNK = 4 * kQ, kNB = 2 * kQ;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   const int tid = threadIdx.x;
@@ -419,9 +429,9 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
   const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
   const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
 
-  vec8<T> qf[kBgNK], dof[kBgNK];
+  vec8<T> qf[kNK], dof[kNK];
 #pragma unroll
-  for (int kk = 0; kk < kBgNK; ++kk) {
+  for (int kk = 0; kk < kNK; ++kk) {
     const int d0 = 16 * kk + 8 * g;
     qf[kk] = d0 < p.D ? *(const vec8<T>*)(qbase + d0) : zero8<T>();
     dof[kk] = d0 < p.D ? *(const vec8<T>*)(dobase + d0) : zero8<T>();
@@ -468,9 +478,9 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
   const uint32_t drop_i = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) + (uint32_t)qrow : 0u;
   const uint32_t drop_j0 = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
-  f32x16 dq[kBgNB];
+  f32x16 dq[kNB];
 #pragma unroll
-  for (int i = 0; i < kBgNB; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
 
@@ -495,11 +505,14 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-        big_gemm<T, 2 * kBgNK, 1>(
-            [&](int i) { return lds_read128<T>(lds_ptr(koff[i & 7]) + ((i >> 4) ? vbo : kbo) + ((i >> 3) & 1) * kBgChunkTile + t * 32 * 256); },
+        big_gemm<T, 2 * kNK, 1>(
+            [&](int i) {                                // i = (0: K tile for S, 1: V tile for dP) * kNK + kk
+              const int kk = i % kNK;
+              return lds_read128<T>(lds_ptr(koff[kk & 7]) + ((i / kNK) ? vbo : kbo) + (kk >> 3) * kBgChunkTile + t * 32 * 256);
+            },
             [&](int i, vec8<T> a) {
-              if (i < kBgNK) s = mfma(a, qf[i & 15], s);
-              else dp = mfma(a, dof[i & 15], dp);
+              if (i < kNK) s = mfma(a, qf[i % kNK], s);
+              else dp = mfma(a, dof[i % kNK], dp);
             });
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = fast_exp2(__builtin_fmaf(s[r], c, -L2));
@@ -525,12 +538,12 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
         for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt);
         {
           const vec8<T> dsb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
-          big_gemm<T, 2 * kBgNB, 2>(
-              [&](int i) {                              // i = ks2 * 8 + dblk
-                const int dblk = i & 7, cimm = kbo + (32 * t + 16 * (i >> 3)) * 256 + (dblk >> 2) * kBgChunkTile;
+          big_gemm<T, 2 * kNB, 2>(
+              [&](int i) {                              // i = ks2 * kNB + dblk
+                const int dblk = i % kNB, cimm = kbo + (32 * t + 16 * (i / kNB)) * 256 + (dblk >> 2) * kBgChunkTile;
                 return concat<T>(lds_read_tr<T>(lds_ptr(toff[dblk & 3][0]) + cimm), lds_read_tr<T>(lds_ptr(toff[dblk & 3][1]) + cimm));
               },
-              [&](int i, vec8<T> a) { dq[i & 7] = mfma(a, dsb[i >> 3], dq[i & 7]); });
+              [&](int i, vec8<T> a) { dq[i % kNB] = mfma(a, dsb[i / kNB], dq[i % kNB]); });
         }
       }
     }
@@ -542,11 +555,11 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
   const int64_t orow = qs.row0 + qrow;
   if (p.dq_acc == nullptr) {
     T* ob = (T*)p.dq + qbatch * p.dq_st.batch + orow * p.dq_st.row + (int64_t)h * p.dq_st.head;
-    store_rows16<T, false, kBgNB>(ob, dq, p.scale, g, p.D, true);
+    store_rows16<T, false, kNB>(ob, dq, p.scale, g, p.D, true);
   } else {
     float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + orow * p.dq_acc_st.row + (int64_t)h * p.dq_acc_st.head;
 #pragma unroll
-    for (int dblk = 0; dblk < kBgNB; ++dblk)
+    for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -592,12 +605,16 @@ __device__ __forceinline__ void wait_vmem64() {
   __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
 }
 
-// kWhich: 0 = dV, 1 = dK.  One launch per tensor: with both accumulator sets (2 x 128 registers) next to the K_w / V_w
-// operands (2 x 64) the arch-VGPR half of the register file overflows (hipcc: 290 accumulator-register moves and 80
-// scratch reloads per tile); a launch that owns one tensor fits, at the price of computing S twice (80 instead of
-// 64 MFMAs per tile and wave).
-template <typename T, int kWhich>
+// kWhich: 0 = dV, 1 = dK, 2 = both.  Head dims > 192 take one launch per tensor: with both accumulator sets (2 x 128
+// registers) next to the K_w / V_w operands (2 x 64) the arch-VGPR half of the register file overflows (hipcc: 290
+// accumulator-register moves and 80 scratch reloads per tile); a launch that owns one tensor fits, at the price of
+// computing S twice (80 instead of 64 MFMAs per tile and wave).  kWhich = 2 at kQ = 3 (head dims <= 192: 2 x 96 + 2 x 48
+// registers, 48 MFMAs per tile and wave instead of 60) is written but NOT launched (-DRFA_BG_FUSED_KV=1): hipcc still
+// allocates it with 1099 accumulator-register moves and 212 bytes of scratch reloaded inside the tile loop (round 4).
+template <typename T, int kWhich, int kQ>
 __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p) {
+  constexpr int kNK = 4 * kQ, kNB = 2 * kQ;
+  constexpr bool kDoK = kWhich != 0, kDoV = kWhich != 1;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   if (lds_addr(smem) & 0xffff) __builtin_trap();     // the stage / fragment XORs below need a 64 KiB-aligned block
@@ -656,16 +673,16 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
 
   // this wave's K and V rows: register B operands of S = Q K_w^T and dP = dO V_w^T
-  vec8<T> kwr[kBgNK], vwr[kWhich ? kBgNK : 1];
+  vec8<T> kwr[kNK], vwr[kDoK ? kNK : 1];
   {
     const int kr = krow < lk ? krow : lk - 1;
     const T* kp = kbase + (int64_t)kr * p.k_st.row;
     const T* vp = vbase + (int64_t)kr * p.v_st.row;
 #pragma unroll
-    for (int kk = 0; kk < kBgNK; ++kk) {
+    for (int kk = 0; kk < kNK; ++kk) {
       const int d0 = 16 * kk + 8 * g;
       kwr[kk] = d0 < p.D ? *(const vec8<T>*)(kp + d0) : zero8<T>();
-      if (kWhich) vwr[kk] = d0 < p.D ? *(const vec8<T>*)(vp + d0) : zero8<T>();
+      if (kDoK) vwr[kk] = d0 < p.D ? *(const vec8<T>*)(vp + d0) : zero8<T>();
     }
   }
 
@@ -739,16 +756,19 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const uint32_t drop_j = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) + (uint32_t)krow : 0u;
   const uint32_t drop_i0 = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
-  f32x16 acc[kBgNB];                                   // dK^T or dV^T of this wave's 32 keys
+  f32x16 acck[kDoK ? kNB : 1], accv[kDoV ? kNB : 1];   // dK^T / dV^T of this wave's 32 keys
 #pragma unroll
-  for (int i = 0; i < kBgNB; ++i)
+  for (int i = 0; i < kNB; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      if (kDoK) acck[i][r] = 0.f;
+      if (kDoV) accv[i][r] = 0.f;
+    }
 
   // dS spill (D == 256, the dK launch; rfa_dqs.hip reads the blocks back — two launches, one per 128-column chunk of
   // K / dQ — instead of dq_big_kernel recomputing S and dP): block (b, h, qt = tile, kb = key / 32) of the scratch,
   // slot order and row layout of rfa_bwd.hip's kSpill instances
-  const bool spill = kWhich == 1 && p.ds != nullptr;
+  const bool spill = kDoK && p.ds != nullptr;
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
   const int ds_nkb = ds_blocks(p.Sk, p.k_half);
   const int64_t ds_head_bytes = spill ? p.ds_head_blocks * kDsBlockBytes : 0;
@@ -776,16 +796,17 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
       for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]
         const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = kWhich ? -dl[e] : 0.f; s[4 * jj + e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = kDoK ? -dl[e] : 0.f; s[4 * jj + e] = 0.f; }
       }
-      big_gemm<T, (kWhich ? 2 : 1) * kBgNK, 1>(
-          [&](int i) {
-            if (!RFA_BG_X_LDS) return kwr[i & 15];
-            return lds_read128<T>(lds_ptr(aq ^ ((i & 7) << 5)) + ((i >> 3) & 1) * kBgQChunk + ((i >> 4) ? kBgOffDo : 0));
+      big_gemm<T, (kDoK ? 2 : 1) * kNK, 1>(
+          [&](int i) {                                  // i = (0: Q tile for S, 1: dO tile for dP) * kNK + kk
+            const int kk = i % kNK;
+            if (!RFA_BG_X_LDS) return kwr[kk];
+            return lds_read128<T>(lds_ptr(aq ^ ((kk & 7) << 5)) + (kk >> 3) * kBgQChunk + ((i / kNK) ? kBgOffDo : 0));
           },
           [&](int i, vec8<T> a) {
-            if (i < kBgNK) s = mfma(a, kwr[i & 15], s);
-            else dp = mfma(a, vwr[kWhich ? (i & 15) : 0], dp);
+            if (i < kNK) s = mfma(a, kwr[i % kNK], s);
+            else dp = mfma(a, vwr[kDoK ? (i % kNK) : 0], dp);
           },
           [&](int i) {                                  // the next tile's DMA pieces in the shadows of the first MFMAs
             if (RFA_BG_X_DMA && i < kPieces) issue_piece(nxt, i);
@@ -806,6 +827,8 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
           s[r] = ok ? s[r] : 0.f;
         }
       }
+      // from here on: s = dS = P (dP - delta) for the dK GEMM, pv = the (dropped, rescaled) P for the dV GEMM
+      f32x16 pv;
       if (drop) {
         // the dK/dV kernel's dropout (rfa_bwd.hip): dP = keep ? dO V^T / (1 - p) : 0, dS = P (dP - delta), dV takes keep ? P / (1 - p) : 0
         const uint32_t hkey = drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)(h0 + cg));
@@ -817,20 +840,33 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
             const int r = 4 * jj + e;
             const uint32_t w = drop_word(hkey, drop_i0 + (uint32_t)(qs0 + crow(r, g)), drop_j >> 2);
             const bool keep = drop_keep(w, (int)(drop_j & 3u), p.drop_keep);
-            if (kWhich) {
+            if (kDoV) pv[r] = keep ? s[r] * p.drop_scale : 0.f;   // dropped, rescaled P
+            if (kDoK) {
               const float dpd = keep ? (dp[r] + dl[e]) * p.drop_scale - dl[e] : -dl[e];
               s[r] = dpd * s[r];                       // dS
-            } else {
-              s[r] = keep ? s[r] * p.drop_scale : 0.f;   // dropped, rescaled P
             }
           }
         }
-      } else if (kWhich) {
+      } else if (kDoV) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= dp[r];    // dS = P (dP - delta)
+        for (int r = 0; r < 16; ++r) pv[r] = s[r];
       }
       // dV^T += dO^T P   /   dK^T += Q^T dS: A operands by transpose reads of the dO / Q tile, B = the packed registers
-      {
+      if (kDoV) {
+        const vec8<T> pb[2] = {pack8<T>(pv, 0), pack8<T>(pv, 8)};
+        big_gemm<T, 2 * kNB, 2>(
+            [&](int i) {                                // i = ks2 * kNB + dblk
+              const int dblk = i % kNB, imm = 16 * (i / kNB) * 256 + (dblk >> 2) * kBgQChunk + kBgOffDo;
+              if (!RFA_BG_X_LDS) return kwr[i % kNK];
+              return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
+            },
+            [&](int i, vec8<T> a) { accv[i % kNB] = mfma(a, pb[i / kNB], accv[i % kNB]); });
+      }
+      if (kDoK) {
+        if (!drop) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] *= dp[r];  // dS = P (dP - delta)
+        }
         const vec8<T> pb[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
         if (spill) {
           const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes + (ds_rowpart(p, j, (qs.row0 >> 5) + b, ds_nkb) + ds_kb) * kDsBlockBytes;
@@ -838,13 +874,13 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[0]), rb, ds_lane, 0, 2);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pb[1]), rb, ds_lane + 128, 0, 2);
         }
-        big_gemm<T, 2 * kBgNB, 2>(
-            [&](int i) {                                // i = ks2 * 8 + dblk
-              const int dblk = i & 7, imm = 16 * (i >> 3) * 256 + (dblk >> 2) * kBgQChunk + (kWhich ? 0 : kBgOffDo);
-              if (!RFA_BG_X_LDS) return kwr[i & 15];
+        big_gemm<T, 2 * kNB, 2>(
+            [&](int i) {                                // i = ks2 * kNB + dblk
+              const int dblk = i % kNB, imm = 16 * (i / kNB) * 256 + (dblk >> 2) * kBgQChunk;
+              if (!RFA_BG_X_LDS) return kwr[i % kNK];
               return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
             },
-            [&](int i, vec8<T> a) { acc[i & 7] = mfma(a, pb[i >> 3], acc[i & 7]); });
+            [&](int i, vec8<T> a) { acck[i % kNB] = mfma(a, pb[i / kNB], acck[i % kNB]); });
       }
     }
     if (RFA_BG_X_DMA && !active) {
@@ -862,15 +898,15 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
 
   if (krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
-  {
-    constexpr int which = kWhich ? 0 : 1;              // (the 128-wide kernel's naming: 0 = dK, 1 = dV)
+  auto store = [&](auto whichc, const f32x16 (&acc)[kNB]) {
+    constexpr int which = decltype(whichc)::value;     // (the 128-wide kernel's naming: 0 = dK, 1 = dV)
     const float sc_ = which ? 1.f : p.scale;
     const Strides st = which ? p.dv_st : p.dk_st;
     const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head + (int64_t)qsplit * p.kv_split_stride;
     if (p.kv_f32) {
       float* ob = (float*)(which ? p.dv : p.dk) + eoff;
 #pragma unroll
-      for (int dblk = 0; dblk < kBgNB; ++dblk)
+      for (int dblk = 0; dblk < kNB; ++dblk)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int d0 = 32 * dblk + 8 * jj + 4 * g;
@@ -882,9 +918,11 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
           }
         }
     } else {
-      store_rows16<T, false, kBgNB>((T*)(which ? p.dv : p.dk) + eoff, acc, sc_, g, p.D, true);
+      store_rows16<T, false, kNB>((T*)(which ? p.dv : p.dk) + eoff, acc, sc_, g, p.D, true);
     }
-  }
+  };
+  if constexpr (kDoK) store(std::integral_constant<int, 0>{}, acck);
+  if constexpr (kDoV) store(std::integral_constant<int, 1>{}, accv);
 }
 
 // ------------------------------------------------------------------------------------
@@ -898,35 +936,50 @@ static int launch_big(K kernel, const P& p, int64_t nblocks, int smem, std::atom
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
+// kQ = 3: head dims <= 192 run without the k-steps / column blocks of the all-padding last quarter (25 % of the MFMAs of
+// a 256-wide row); the LDS tile stays [rows][256] (its missing chunks are zero-filled by the DMA's range check)
+template <typename T, int kQ>
+static int launch_fwd_big_t(const FwdParams& p, int64_t n, hipStream_t stream) {
+  static std::atomic<unsigned long long> done{0};
+  return launch_big(fwd_big_kernel<T, kQ>, p, n, kBgFwdSmem, done, stream);
+}
 int launch_fwd_big(const FwdParams& p0, int dtype, hipStream_t stream) {
-  static std::atomic<unsigned long long> done_b{0}, done_h{0};
   FwdParams p = p0;
   p.nqblk = (big_len(p.Sq, p.q_half) + kBgRows - 1) / kBgRows;
   const int64_t n = (int64_t)p.nqblk * p.H * p.B;
-  return dtype == 0 ? launch_big(fwd_big_kernel<bf16_t>, p, n, kBgFwdSmem, done_b, stream)
-                    : launch_big(fwd_big_kernel<f16_t>, p, n, kBgFwdSmem, done_h, stream);
+  if (p.D <= 192) return dtype == 0 ? launch_fwd_big_t<bf16_t, 3>(p, n, stream) : launch_fwd_big_t<f16_t, 3>(p, n, stream);
+  return dtype == 0 ? launch_fwd_big_t<bf16_t, 4>(p, n, stream) : launch_fwd_big_t<f16_t, 4>(p, n, stream);
 }
 
+template <typename T, int kQ>
+static int launch_dq_big_t(const BwdParams& p, int64_t n, hipStream_t stream) {
+  static std::atomic<unsigned long long> done{0};
+  return launch_big(dq_big_kernel<T, kQ>, p, n, kBgFwdSmem, done, stream);
+}
 int launch_bwd_dq_big(const BwdParams& p0, int dtype, hipStream_t stream) {
-  static std::atomic<unsigned long long> done_b{0}, done_h{0};
   BwdParams p = p0;
   p.nqblk = (big_len(p.Sq, p.q_half) + kBgRows - 1) / kBgRows;
   const int64_t n = (int64_t)p.nqblk * p.H * p.B;
-  return dtype == 0 ? launch_big(dq_big_kernel<bf16_t>, p, n, kBgFwdSmem, done_b, stream)
-                    : launch_big(dq_big_kernel<f16_t>, p, n, kBgFwdSmem, done_h, stream);
+  if (p.D <= 192) return dtype == 0 ? launch_dq_big_t<bf16_t, 3>(p, n, stream) : launch_dq_big_t<f16_t, 3>(p, n, stream);
+  return dtype == 0 ? launch_dq_big_t<bf16_t, 4>(p, n, stream) : launch_dq_big_t<f16_t, 4>(p, n, stream);
 }
 
+template <typename T, int kQ>
+static int launch_dkdv_big_t(const BwdParams& p, int64_t n, hipStream_t stream) {
+  static std::atomic<unsigned long long> done[2];
+#if RFA_BG_FUSED_KV
+  if constexpr (kQ == 3) return launch_big(dkdv_big_kernel<T, 2, kQ>, p, n, kBgKvSmem, done[0], stream);
+#endif
+  if (int rc = launch_big(dkdv_big_kernel<T, 0, kQ>, p, n, kBgKvSmem, done[0], stream)) return rc;
+  return launch_big(dkdv_big_kernel<T, 1, kQ>, p, n, kBgKvSmem, done[1], stream);
+}
 int launch_bwd_dkdv_big(const BwdParams& p0, int dtype, hipStream_t stream) {
-  static std::atomic<unsigned long long> done[4];
   BwdParams p = p0;
   p.nkblk = (big_len(p.Sk, p.k_half) + kBgRows - 1) / kBgRows;
   if (p.nsplit < 1) p.nsplit = 1;
   const int64_t n = (int64_t)p.nkblk * p.Hk * p.B * p.nsplit;
-  int rc = dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t, 0>, p, n, kBgKvSmem, done[0], stream)
-                      : launch_big(dkdv_big_kernel<f16_t, 0>, p, n, kBgKvSmem, done[1], stream);
-  if (rc) return rc;
-  return dtype == 0 ? launch_big(dkdv_big_kernel<bf16_t, 1>, p, n, kBgKvSmem, done[2], stream)
-                    : launch_big(dkdv_big_kernel<f16_t, 1>, p, n, kBgKvSmem, done[3], stream);
+  if (p.D <= 192) return dtype == 0 ? launch_dkdv_big_t<bf16_t, 3>(p, n, stream) : launch_dkdv_big_t<f16_t, 3>(p, n, stream);
+  return dtype == 0 ? launch_dkdv_big_t<bf16_t, 4>(p, n, stream) : launch_dkdv_big_t<f16_t, 4>(p, n, stream);
 }
 
 }  // namespace rfa

@@ -131,7 +131,9 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   for (int i = 0; i < Geo::kKPieces; ++i) {
     const int row = 4 * (wave + kW * i) + (lane >> 4);
     const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
-    voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
+    // (p.D < 128: the second 128-column chunk of a head dim 136 .. 248 — the lanes of its missing 16-byte chunks point past
+    //  every descriptor range and write zeros, as in rfa_bigd.hip)
+    voff_k[i] = chunk * 8 < p.D ? (row * (int)p.k_st.row + chunk * 8) * 2 : 0x7ffffff0;
   }
   const int voff_s = lane * 16;
   auto load_tile = [&](int j, auto stage) {
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   if (qrow >= lq) return;
   if (p.dq_acc == nullptr) {
     T* ob = (T*)p.dq + qbatch * p.dq_st.batch + (qs.row0 + qrow) * p.dq_st.row + (int64_t)h * p.dq_st.head;
-    store_rows16<T, true>(ob, dq, p.scale, g, p.D, true);
+    store_rows16<T, false>(ob, dq, p.scale, g, p.D, true);
   } else {
     float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + (qs.row0 + qrow) * p.dq_acc_st.row +
                 (int64_t)h * p.dq_acc_st.head;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
+        if (d0 >= p.D) continue;
         f32x4 x;
         if (p.acc_init) {
 #pragma unroll
@@ -288,12 +291,12 @@ static int launch_dq_ds_t(const BwdParams& p, hipStream_t stream) {
 }
 
 int launch_bwd_dq_from_ds(const BwdParams& p, int dtype, hipStream_t stream) {
-  if (p.D == 2 * kHeadDim) {
-    // head dim 256 (dS written by rfa_bigd.hip's dK launch): dQ[:, c] = scale dS K[:, c] per 128-column chunk c — the same
-    // kernel twice, on column-offset views of K and dQ
+  if (p.D > kHeadDim) {
+    // head dims 136 .. 256 (dS written by rfa_bigd.hip's dK launch): dQ[:, c] = scale dS K[:, c] per 128-column chunk c —
+    // the same kernel twice, on column-offset views of K and dQ (the second chunk has D - 128 columns)
     for (int c = 0; c < 2; ++c) {
       BwdParams pc = p;
-      pc.D = kHeadDim;
+      pc.D = c == 0 ? kHeadDim : p.D - kHeadDim;
       pc.k = (const char*)p.k + (size_t)c * kHeadDim * 2;
       if (p.dq_acc) pc.dq_acc = p.dq_acc + c * kHeadDim;
       else pc.dq = (char*)p.dq + (size_t)c * kHeadDim * 2;

@@ -41,6 +41,7 @@ def _oracle(q, k, v, do, causal, window=(-1, -1), cu=None, drop=None):
     (160, 1, 1000, 1000, 2, 2, True, torch.float16),
     (136, 1, 260, 130, 2, 1, True, BF),            # one 16-byte chunk beyond 128; rows without a visible key
     (256, 1, 2500, 2500, 2, 1, True, BF),          # many tiles (both LDS stages, every wave role)
+    (192, 1, 2500, 2500, 2, 1, True, BF),          # ... in the three-quarter instances (head dims <= 192 skip the padding quarter)
 ])
 def test_dense_forward_backward(D, B, Sq, Sk, H, Hk, causal, dtype):
     from ring_flash_attn.backend import get_backend, set_backend
@@ -78,20 +79,23 @@ def test_dense_forward_backward(D, B, Sq, Sk, H, Hk, causal, dtype):
     _grads_ok(f"d{D}.acc2", (dqa / 2, dka / 2, dva / 2), (rdq, rdk, rdv))
 
 
-@pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk", [
-    (1024, 1024, True, 1, 4, 2),      # dense causal: triangular scratch, query range shared by 2 - 4 workgroups
-    (300, 901, True, 2, 2, 2),        # bottom-right aligned, ragged
-    (640, 384, False, 1, 2, 1),       # rectangular scratch
+@pytest.mark.parametrize("Sq,Sk,causal,B,H,Hk,D", [
+    (1024, 1024, True, 1, 4, 2, 256),      # dense causal: triangular scratch, query range shared by 2 - 4 workgroups
+    (300, 901, True, 2, 2, 2, 256),        # bottom-right aligned, ragged
+    (640, 384, False, 1, 2, 1, 256),       # rectangular scratch
+    (1024, 1024, True, 1, 4, 2, 192),      # second 128-column launch of rfa_dqs.hip with 64 columns (zero-filled K lanes)
+    (300, 901, True, 2, 2, 2, 136),        # ... with 8 columns
+    (640, 384, False, 1, 2, 1, 160),
 ])
-def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk):
-    """the 5-GEMM backward at D = 256 (the dK launch of rfa_bigd.hip stores dS, rfa_dqs.hip computes dQ from it in two
-    128-column launches) against the oracle, against the 7-GEMM form (dK / dV bit-identical: the same kernel with and
-    without the stores)"""
+def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk, D):
+    """the 5-GEMM backward at D = 136 .. 256 (the dK launch of rfa_bigd.hip stores dS, rfa_dqs.hip computes dQ from it in
+    two 128-column launches, the second over the D - 128 columns that exist) against the oracle, against the 7-GEMM form
+    (dK / dV bit-identical: the same kernel with and without the stores)"""
     from ring_flash_attn.backend import get_backend, set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
-    D = 256
+    assert be.lib.rfa_bwd_ds_scratch_bytes is not None
     g = torch.Generator().manual_seed(Sq + Sk)
     q, k, v = (torch.randn(B, s_, h_, D, generator=g).to(BF) for s_, h_ in ((Sq, H), (Sk, Hk), (Sk, Hk)))
     do = torch.randn(B, Sq, H, D, generator=g).to(BF)
@@ -107,14 +111,14 @@ def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk
         monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
         dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
         be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv)
-        _grads_ok(f"d256.spill{spill}", (dq, dk, dv), (rdq, rdk, rdv))
+        _grads_ok(f"d{D}.spill{spill}", (dq, dk, dv), (rdq, rdk, rdv))
         res[spill] = (dq, dk, dv)
     assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
     monkeypatch.setenv("RFA_BWD_DS_SPILL", "1")
     dqa = torch.zeros(B, Sq, H, D, dtype=torch.float32, device=dev)
     dka, dva = (torch.empty(B, Sk, Hk, D, dtype=torch.float32, device=dev) for _ in range(2))
     be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq_acc=dqa, dk_acc=dka, dv_acc=dva, acc_init=True)
-    _grads_ok("d256.spill.acc", (dqa, dka, dva), (rdq, rdk, rdv))
+    _grads_ok(f"d{D}.spill.acc", (dqa, dka, dva), (rdq, rdk, rdv))
 
 
 def test_forward_merge_of_two_key_halves_equals_one_call():
