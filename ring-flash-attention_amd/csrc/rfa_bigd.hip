@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[1][r]);
-      mloc = fmaxf(mloc, shfl_xor32(mloc));
+      mloc = max_xor32(mloc);               // v_permlane32_swap, no LDS round trip (rfa_common.hpp)
       const float mnew = fmaxf(m, mloc);
       // deferred rescale as in rfa_fwd.hip: while no row of the wave grew its max by more than 8 log2 units the stale
       // max stays (P <= 2^8, exact in fp32) and the 128-register rescale of O — accumulator registers read, scaled
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
   }
 
   if (qrow >= lq) return;
-  const float l = lsum + shfl_xor32(lsum);
+  const float l = sum_xor32(lsum);
   const bool has = l > 0.f;
   const float inv = has ? (drop ? p.drop_scale : 1.f) / l : 0.f;
   const float blse = has ? m * p.scale + __logf(l) : INFINITY;

@@ -58,7 +58,11 @@
 #define RFA_KV_X_SYNC 1
 #endif
 #ifndef RFA_KV_PRIO
-#define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
+#define RFA_KV_PRIO 4        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
+                             // (neutral); s_setprio 1 around 3: the dP / S GEMM pair, 4: the dV / dK GEMM pair, 5: both.  Round 4 A/B
+                             // of the headline launch (profiles/r04_dkdv_variants.txt, two passes each): 0 -> 1.0870 ms, 3 -> 1.0836,
+                             // 4 -> 1.0788, 5 -> 1.0965: the wave that is in its transpose-read / MFMA phase wins the arbitration
+                             // against its SIMD partner's exponentials
 #endif
 #ifndef RFA_SPILL_AUX
 #define RFA_SPILL_AUX 2      // cache policy bits of the dS spill stores: 2 = nt (streamed once; 0: dkdv +3 %)
@@ -683,6 +687,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (active) {
       ++nact;
       f32x16 s, dp;
+      if (RFA_KV_PRIO == 3 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]: 4 LDS reads, no VALU
         const f32x4 nd = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kKvQ + 8 * jj) * 4);
@@ -727,6 +732,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
 #endif
       }
+      if (RFA_KV_PRIO == 3 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(0);
       // lse is read only now: holding it across GEMM 1 would cost 16 registers
       f32x4 l2v[4];
 #pragma unroll
@@ -790,6 +796,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds1), rb, ds_lane + 128, 0, RFA_SPILL_AUX);
         };
         if (RFA_SPILL_PROBE != 2) spill();
+        if (RFA_KV_PRIO == 4 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(1);
         constexpr int kAhead = RFA_KV_AHEAD2;
         constexpr int kN2 = 4 * kNB;                   // [ks2][which: 0 = dO^T (dV), 1 = Q^T (dK)][dblk]
         vec8<T> a[kN2];
@@ -821,6 +828,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         }
         __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 1);
 #endif
+        if (RFA_KV_PRIO == 4 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(0);
         if (RFA_SPILL_PROBE == 2) spill();
       }
     }

@@ -313,6 +313,19 @@ __device__ __forceinline__ bool drop_keep(uint32_t word, int byte, uint32_t keep
 }
 
 __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 64); }
+// max / sum of a value over the two half-waves (lane l and lane l ^ 32) WITHOUT the LDS round trip of a
+// ds_bpermute: v_permlane32_swap of a register with a copy of itself leaves {lower half, lower half} in one and
+// {upper half, upper half} in the other, so one swap + one max (add) gives every lane the combined value.
+__device__ __forceinline__ float max_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 

@@ -25,7 +25,19 @@
                              //  'spike keys' self-test cases that force the rescale branch mid-loop)
 #endif
 #ifndef RFA_FWD_AHEAD
-#define RFA_FWD_AHEAD 4
+#define RFA_FWD_AHEAD 6      // K fragments read ahead of their MFMA in the S GEMM (round 4 A/B, one box, two passes each:
+                             // 2 -> 0.5015 ms, 4 -> 0.4857, 6 -> 0.4835, 8 -> 0.4855)
+#endif
+#ifndef RFA_FWD_MAXFORM
+#define RFA_FWD_MAXFORM 1    // the half-wave exchange of the row max / row sum: 0 ds_bpermute (__shfl_xor: an LDS round trip plus
+                             // six address instructions per tile), 1 v_permlane32_swap (rfa_common.hpp: max_xor32).  Same bits.
+                             // Round 4 A/B (profiles/r04_fwd_variants.txt): 0 -> 0.4880 ms, 1 -> 0.4795.  Also measured there and
+                             // NOT kept, all bit-identical: the 31-deep max chain as four independent chains (0.4831: six more
+                             // canonicalising v_max), the first sub-tile's chain in the MFMA shadows of the second sub-tile's
+                             // S GEMM (0.4846), one barrier per TWO tiles on a 4-stage ring (0.4889), s_setprio 1 around the S
+                             // GEMM / the P·V GEMM / both (0.4842 / 0.4849 / 0.4872 against 0.4846), and the row sums as a fifth
+                             // MFMA per k-step with an all-ones A operand instead of 32 v_add per tile (36 MFMAs and 113 VALU
+                             // per tile instead of 32 and 145: 0.4959 against 0.4857 — the matrix pipe's time is not free).
 #endif
 // (Round 4: a software-pipelined tile loop — S of tile j+1 issued inside the softmax of tile j in every wave, two S
 //  register sets, the guide's "att[2]" technique — was built here and removed again: it needs 32 more registers than
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
       for (int t = 1; t < kFwdSub; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
-      mloc = fmaxf(mloc, shfl_xor32(mloc));
+      mloc = RFA_FWD_MAXFORM ? max_xor32(mloc) : fmaxf(mloc, shfl_xor32(mloc));
       const float mnew = fmaxf(m, mloc);
       // deferred rescale (RFA_FWD_DEFER > 0): while no row of the wave grew its max by more than
       // DEFER log2 units, keep the stale max — P is then bounded by 2^DEFER instead of 1, still
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
 
   // ---------------- epilogue ----------------
   if (qrow >= lq) return;
-  const float l = lsum + shfl_xor32(lsum);
+  const float l = RFA_FWD_MAXFORM ? sum_xor32(lsum) : lsum + shfl_xor32(lsum);
   const bool has = l > 0.f;
   const float inv = has ? (kDrop ? p.drop_scale : 1.f) / l : 0.f;      // kept probabilities are scaled by 1 / (1 - p)
   const float blse = has ? m * p.scale + __logf(l) : INFINITY;   // natural log
