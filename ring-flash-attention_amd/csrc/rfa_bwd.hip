@@ -35,10 +35,17 @@
 #define RFA_DQ_AHEAD1 3
 #endif
 #ifndef RFA_KV_AHEAD
-#define RFA_KV_AHEAD 2       // dkdv: fragment pairs read this many MFMAs ahead in the S/dP GEMMs (3, 4: +1.5 %)
+#define RFA_KV_AHEAD 3       // dkdv: fragment pairs read this many MFMAs ahead in the S/dP GEMMs (rounds 1-3, one-body loop: 3, 4 were
+                             // 1.5 % slower than 2; with the unrolled sub-tile bodies 1 -> 1.117 ms, 2 -> 1.098, 3 -> 1.081,
+                             // 4 -> 1.090 against 1.080; not kept from the same runs: the first transposed fragments of the dV / dK pair
+                             // fetched before the exponentials (255 registers, equal), the fragment bases aq ^ (kk << 5) / tq ^ (dblk << 6)
+                             // formed once per tile for both sub-tiles (249 - 255 registers, 0 - 1 % slower), RFA_KV_AHEAD2 3 (slower))
 #endif
 #ifndef RFA_KV_WIDE_UNROLL
-#define RFA_KV_WIDE_UNROLL 0 // dkdv kWide: 1 = the two sub-tile bodies unrolled, 0 = a runtime loop over one body
+#define RFA_KV_WIDE_UNROLL 1 // dkdv kWide: 1 = the two sub-tile bodies unrolled, 0 = a runtime loop over one body.  Round 4, after the mask
+                             // rewrite had freed 15 registers (244 registers, no scratch): the headline launch 1.092 -> 1.063 ms, the whole
+                             // step 2.033 -> 2.000 ms (profiles/r04_dkdv_variants.txt, three passes).  The unrolled bodies address the
+                             // second sub-tile with instruction immediates (+ 32 rows) instead of toggling every fragment base
 #endif
 #ifndef RFA_KV_AHEAD2
 #define RFA_KV_AHEAD2 2      // dkdv: transpose-read fragment pairs ahead in the dV/dK GEMMs
@@ -58,11 +65,11 @@
 #define RFA_KV_X_SYNC 1
 #endif
 #ifndef RFA_KV_PRIO
-#define RFA_KV_PRIO 4        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
-                             // (neutral); s_setprio 1 around 3: the dP / S GEMM pair, 4: the dV / dK GEMM pair, 5: both.  Round 4 A/B
-                             // of the headline launch (profiles/r04_dkdv_variants.txt, two passes each): 0 -> 1.0870 ms, 3 -> 1.0836,
-                             // 4 -> 1.0788, 5 -> 1.0965: the wave that is in its transpose-read / MFMA phase wins the arbitration
-                             // against its SIMD partner's exponentials
+#define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
+                             // (neutral); s_setprio 1 around 3: the dP / S GEMM pair, 4: the dV / dK GEMM pair, 5: both.  Round 4 A/B of
+                             // the headline launch (profiles/r04_dkdv_variants.txt): with the one-body loop 0 -> 1.0870 ms, 3 -> 1.0836,
+                             // 4 -> 1.0788, 5 -> 1.0965; with the two sub-tile bodies unrolled (the default now) 4 and 0 are equal
+                             // (whole step 2.001 vs 1.994 ms over three passes), so the default stays 0
 #endif
 #ifndef RFA_SPILL_AUX
 #define RFA_SPILL_AUX 2      // cache policy bits of the dS spill stores: 2 = nt (streamed once; 0: dkdv +3 %)
@@ -681,6 +688,10 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #endif
     for (int t0 = 0; t0 < (kWide ? 2 : 1); ++t0) {
     const int t = kWide ? t0 : par;
+    // unrolled kWide bodies: the sub-tile is an IMMEDIATE on every LDS access (the bases have address bit 13 — rows 32..63
+    // of a tile — and bit 7 — the statistics of those rows — clear, so adding equals toggling)
+    constexpr bool kImm = kWide && RFA_KV_WIDE_UNROLL;
+    const int toff = kImm ? t0 * 32 * kRowBytes : 0, soff_t = kImm ? t0 * 32 * 4 : 0;
     const int qs0 = j * kKvQ + 32 * t;
     active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) &&
              !(lo && qs0 + off - wl > kw0 + 31);
@@ -690,7 +701,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       if (RFA_KV_PRIO == 3 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {               // dp starts at -delta[q]: 4 LDS reads, no VALU
-        const f32x4 nd = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kKvQ + 8 * jj) * 4);
+        const f32x4 nd = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + (kKvQ + 8 * jj) * 4 + soff_t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { dp[4 * jj + e] = nd[e]; s[4 * jj + e] = 0.f; }
       }
@@ -702,7 +713,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         vec8<T> a[kN], w[kNK];
         auto fa = [&](int i) {
           if (!RFA_KV_X_LDS) return kwr[i % kNK];
-          return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0));
+          return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0) + toff);
         };
         auto fw = [&](int i) {
           if (!RFA_KV_X_LDS) return kwr[i];
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       // lse is read only now: holding it across GEMM 1 would cost 16 registers
       f32x4 l2v[4];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
+      for (int jj = 0; jj < 4; ++jj) l2v[jj] = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4 + soff_t);
       const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) ||
                              (lo && qs0 + 31 + off - wl > kw0);
 #pragma unroll
@@ -804,7 +815,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
           const int ks2 = i / (2 * kNB), which = (i / kNB) & 1, dblk = i % kNB;
           constexpr int kPer = Geo::kSwzRows;
           const int kv = (16 * ks2 % kPer) / 16;
-          const int imm = (which ? 0 : kOffDo) + (16 * ks2 / kPer) * kPer * kRowBytes;
+          const int imm = (which ? 0 : kOffDo) + (16 * ks2 / kPer) * kPer * kRowBytes + toff;
           if (!RFA_KV_X_LDS) return kwr[i % kNK];
           vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[kv][0] ^ (dblk << 6)) + imm);
           vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[kv][1] ^ (dblk << 6)) + imm);
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         if (RFA_SPILL_PROBE == 2) spill();
       }
     }
-    if (kWide) {
+    if (kWide && !kImm) {
       aq ^= 32 * kRowBytes;
 #pragma unroll
       for (int kv = 0; kv < kTK; ++kv) {

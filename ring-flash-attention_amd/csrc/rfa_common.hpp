@@ -319,7 +319,11 @@ __device__ __forceinline__ float shfl_xor32(float v) { return __shfl_xor(v, 32, 
 __device__ __forceinline__ float max_xor32(float v) {
   const unsigned u = __builtin_bit_cast(unsigned, v);
   auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+  // (one v_max_f32 through asm: fmaxf() on values the compiler cannot see through first canonicalises both operands
+  //  with a v_max x, x each — three instructions for one)
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"((unsigned)r[0]), "v"((unsigned)r[1]));
+  return d;
 }
 __device__ __forceinline__ float sum_xor32(float v) {
   const unsigned u = __builtin_bit_cast(unsigned, v);

@@ -28,6 +28,12 @@
 #define RFA_FWD_AHEAD 6      // K fragments read ahead of their MFMA in the S GEMM (round 4 A/B, one box, two passes each:
                              // 2 -> 0.5015 ms, 4 -> 0.4857, 6 -> 0.4835, 8 -> 0.4855)
 #endif
+#ifndef RFA_FWD_LEAN
+#define RFA_FWD_LEAN 1       // 1: the deferred-rescale test is ONE compare of the tile's row max against a threshold kept per
+                             // row (running max + DEFER / c) and the scaled running max (-m c, the addend of the exponent FMA) is
+                             // kept in a register, both updated only where the rescale branch runs: 2 VALU instructions per tile
+                             // between the half-wave exchange and the exponentials instead of 7 + a wait state
+#endif
 #ifndef RFA_FWD_MAXFORM
 #define RFA_FWD_MAXFORM 1    // the half-wave exchange of the row max / row sum: 0 ds_bpermute (__shfl_xor: an LDS round trip plus
                              // six address instructions per tile), 1 v_permlane32_swap (rfa_common.hpp: max_xor32).  Same bits.
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   const uint32_t drop_j0 = kDrop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) : 0u;
   const float c = p.scale * kLog2e;
   float m = -INFINITY;
+  float mthr = -INFINITY, mc_run = 0.f;      // RFA_FWD_LEAN: rescale threshold m + DEFER / c, and m c (0 while m is -inf)
   float lsum = 0.f;
   f32x16 o[kNB];
 #pragma unroll
@@ -339,23 +346,32 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
       mloc = RFA_FWD_MAXFORM ? max_xor32(mloc) : fmaxf(mloc, shfl_xor32(mloc));
-      const float mnew = fmaxf(m, mloc);
       // deferred rescale (RFA_FWD_DEFER > 0): while no row of the wave grew its max by more than
       // DEFER log2 units, keep the stale max — P is then bounded by 2^DEFER instead of 1, still
       // exact in fp32 / same relative precision in bf16 — and skip the 64-register O rescale.
+      // RFA_FWD_LEAN: "grew by more than DEFER" is mloc > mthr with mthr = m + DEFER / c (-inf while m is -inf: a row
+      // without a visible key so far has nothing to rescale), and mc = m c is carried instead of recomputed per tile.
       bool rescale = true;
-      if (RFA_FWD_DEFER > 0) rescale = !__all((mnew - m) * c <= (float)RFA_FWD_DEFER);
+      if (RFA_FWD_LEAN) {
+        rescale = !__all(mloc <= mthr);
+      } else {
+        const float mnew0 = fmaxf(m, mloc);
+        if (RFA_FWD_DEFER > 0) rescale = !__all((mnew0 - m) * c <= (float)RFA_FWD_DEFER);
+      }
       if (rescale) {
+        const float mnew = fmaxf(m, mloc);
         const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
         const float alpha = fast_exp2(m * c - msafe * c);
         m = mnew;
+        mc_run = msafe * c;
+        mthr = mnew + (RFA_FWD_DEFER > 0 ? (float)RFA_FWD_DEFER / c : 0.f);      // (-inf stays -inf)
         lsum *= alpha;
 #pragma unroll
         for (int i = 0; i < kNB; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
       }
-      const float mc = ((m == -INFINITY) ? 0.f : m) * c;
+      const float mc = RFA_FWD_LEAN ? mc_run : ((m == -INFINITY) ? 0.f : m) * c;
 #if RFA_FWD_PACKED_VALU
       // scale / subtract and the row sum as whole-vector expressions: hipcc turns them into v_pk_fma_f32 / v_pk_add_f32
       // (two fp32 per lane and instruction) — 32 VALU instructions fewer per tile than the element-wise form
