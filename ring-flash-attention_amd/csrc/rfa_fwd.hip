@@ -43,7 +43,10 @@
                              // S GEMM (0.4846), one barrier per TWO tiles on a 4-stage ring (0.4889), s_setprio 1 around the S
                              // GEMM / the P·V GEMM / both (0.4842 / 0.4849 / 0.4872 against 0.4846), and the row sums as a fifth
                              // MFMA per k-step with an all-ones A operand instead of 32 v_add per tile (36 MFMAs and 113 VALU
-                             // per tile instead of 32 and 145: 0.4959 against 0.4857 — the matrix pipe's time is not free).
+                             // per tile instead of 32 and 145: 0.4959 against 0.4857 — the matrix pipe's time is not free); with a
+                             // 3-stage ring, the tile's barrier between the S GEMM and the softmax instead of behind P·V, so that
+                             // a wave runs from P·V straight into the next S GEMM (0.5328 against 0.5123: the common restart
+                             // behind the barrier is worth more than the seam it removes).
 #endif
 // (Round 4: a software-pipelined tile loop — S of tile j+1 issued inside the softmax of tile j in every wave, two S
 //  register sets, the guide's "att[2]" technique — was built here and removed again: it needs 32 more registers than
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
     for (int kv = 0; kv < kVK; ++kv)
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        voff[dblk][kv][hh] = lds_addr(smem) + tr_off_d<kD>(lane, dblk, 16 * kv + 8 * hh + 4 * g);
+        voff[dblk][kv][hh] = lds_addr(smem) + kFwdStages * kFwdTileBytes + tr_off_d<kD>(lane, dblk, 16 * kv + 8 * hh + 4 * g);   // (incl. the V region's base: the immediates stay below 64 KiB with 3 stages too)
         pin_vgpr(voff[dblk][kv][hh]);
       }
 
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   auto tile_step = [&](int j, auto stage) {
     constexpr int kStage = decltype(stage)::value;
     constexpr int kbo = kStage * kFwdTileBytes;                   // K stage
-    constexpr int vbo = (kFwdStages + kStage) * kFwdTileBytes;    // V stage
+    constexpr int vbo = kStage * kFwdTileBytes;                   // V stage, relative to the V region (whose base is part of voff)
     typedef std::integral_constant<int, (kStage + kDist) % kFwdStages> fill_t;   // stage refilled now
     typedef std::integral_constant<int, (kStage + 1) % kFwdStages> next_t;
     const bool more = j + kDist < ntiles;
