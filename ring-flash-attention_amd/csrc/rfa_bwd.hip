@@ -87,7 +87,7 @@ constexpr int kDqWaves = 8;
 constexpr int kDqThreads = kDqWaves * 64;
 constexpr int kDqRows = kDqWaves * 32;          // 256 query rows / workgroup
 constexpr int kDqKV = 64;
-template <int kD> constexpr int dq_smem() { return 4 * kDqKV * kD * 2; }   // K[2] V[2]
+template <int kD> constexpr int dq_smem() { return 4 * kDqKV * HeadGeo<kD>::kRowBytes; }   // K[2] V[2]
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging), else zero padded (register staging)
 // kDrop: dropout (the forward's mask, rfa_common.hpp: drop_word) applied to dP; instances without a window only
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
   constexpr int kDqTileBytes = kDqKV * kRowBytes;            // 16 KiB (8 KiB at kD = 64)
   constexpr int kShare = kDqTileBytes / 1024 / kDqWaves;     // 1 KiB DMA pieces per wave and tile
-  constexpr int kChunks = kD / 8;
+  constexpr int kChunks = Geo::kLay / 8;
   constexpr int kRowsPerPass = kDqThreads / kChunks;
 
   const int tid = threadIdx.x;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;
-  const bool sd_ok = kFullD || sc * 8 < p.D;
+  const bool sd_ok = (kFullD && kD == Geo::kLay) || sc * 8 < p.D;   // (kD = 96: the layout's chunks 12..15 are not part of the head)
   // K/V tiles are fetched with raw buffer loads (fixed per-thread byte offsets, the tile advance lives in
   // the scalar descriptor, rows past the end of the sequence read as zero).  With D == 128 they go
   // global -> LDS directly (buffer_load ... lds): a wave-instruction fills 64 consecutive 16-byte slots =
@@ -397,7 +397,7 @@ constexpr int kKvKeys = 128;                       // keys / workgroup
 constexpr int kKvQ = 64;                           // query rows per tile (2 sub-tiles of 32)
 constexpr int kKvStatBytes = 2 * kKvQ * 4;         // lse[64] + delta[64] per stage
 template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64)
-  return 2 * kKvKeys * kD * 2 + 4 * kKvQ * kD * 2 + 2 * kKvStatBytes;
+  return 2 * kKvKeys * HeadGeo<kD>::kRowBytes + 4 * kKvQ * HeadGeo<kD>::kRowBytes + 2 * kKvStatBytes;
 }
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging) else zero padded (register staging);
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
   constexpr int kKvTileBytes = kKvQ * kRowBytes;             // 16 KiB (8 KiB at kD = 64)
   constexpr int kKvKvBytes = kKvKeys * kRowBytes;            // 32 KiB (16 KiB) per 128 keys
-  constexpr int kChunks = kD / 8;
+  constexpr int kChunks = Geo::kLay / 8;
   constexpr int kRowsPerPass = kKvThreads / kChunks;         // register staging: one chunk per thread and pass
   constexpr int kPasses = kKvQ / kRowsPerPass;               // passes (= 1 KiB DMA pieces per wave) per Q / dO tile
   constexpr int kTK = Geo::kSwzRows / 16;                    // k-steps of a transpose read that need their own address
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
-  const bool sd_ok = kFullD || sc * 8 < p.D;
+  const bool sd_ok = (kFullD && kD == Geo::kLay) || sc * 8 < p.D;   // (kD = 96: the layout's chunks 12..15 are not part of the head)
 
   // ---- V rows of the workgroup go to LDS once (128 rows x kChunks chunks); this wave's
   // K rows stay in registers as the B operand of the S GEMM (4 kNK registers)
@@ -964,6 +964,10 @@ static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
 template <typename T, bool kWin, bool kDrop>
 static int launch_dq_d(const BwdParams& p, hipStream_t stream) {
   if (p.D == 128) return launch_dq_t<T, 128, true, kWin, kDrop>(p, stream);
+  if constexpr (!kWin && !kDrop) {          // 64 < D <= 96: the 128-wide layout with three quarters of the MFMA work
+    if (p.D == 96) return launch_dq_t<T, 96, true, kWin, kDrop>(p, stream);
+    if (p.D > 64 && p.D < 96) return launch_dq_t<T, 96, false, kWin, kDrop>(p, stream);
+  }
   if (p.D > 64) return launch_dq_t<T, 128, false, kWin, kDrop>(p, stream);
   if (p.D == 64) return launch_dq_t<T, 64, true, kWin, kDrop>(p, stream);
   return launch_dq_t<T, 64, false, kWin, kDrop>(p, stream);
@@ -977,6 +981,10 @@ int launch_bwd_dq(const BwdParams& p, int dtype, hipStream_t stream) {
 template <typename T, bool kWin, bool kDrop>
 static int launch_dkdv_d(const BwdParams& p, hipStream_t stream) {
   if (p.D == 128) return launch_dkdv_t<T, 128, true, false, kWin, false, kDrop>(p, stream);
+  if constexpr (!kWin && !kDrop) {          // 64 < D <= 96: the 128-wide layout with three quarters of the MFMA work
+    if (p.D == 96) return launch_dkdv_t<T, 96, true, false, kWin, false, kDrop>(p, stream);
+    if (p.D > 64 && p.D < 96) return launch_dkdv_t<T, 96, false, false, kWin, false, kDrop>(p, stream);
+  }
   if (p.D > 64) return launch_dkdv_t<T, 128, false, false, kWin, false, kDrop>(p, stream);
   if (p.D == 64) return launch_dkdv_t<T, 64, true, false, kWin, false, kDrop>(p, stream);
   return launch_dkdv_t<T, 64, false, false, kWin, false, kDrop>(p, stream);

@@ -84,23 +84,25 @@ __device__ __forceinline__ vec4<T> lds_read_tr(lds_t* p) {
 }
 
 // ---- head-dim geometry -------------------------------------------------------------------------------
-// The attention kernels are compiled for kD = 128 and kD = 64 (runtime D <= kD, zero padded).  LDS tiles always
+// The attention kernels are compiled for kD = 128, 96 and 64 (runtime D <= kD, zero padded; 96 = the 128-wide LDS layout
+// with three instead of four 32-column blocks of MFMA work: 6 k-steps over d, 3 accumulator tiles).  LDS tiles always
 // use 256-byte PHYSICAL rows so that the one swizzle above serves both: with kD = 64 a physical row holds two
 // logical rows (logical row r, 16-byte chunk c in 0..7 -> physical row r >> 1, chunk ((r & 1) << 3) | c).  Both
 // conflict properties carry over: a 16-lane ds_read_b128 group (16 distinct rows, one chunk) still sees 16
 // distinct 16-byte slots, and the 4-row x 64-byte footprint of a transpose read still covers 256 distinct bytes.
 template <int kD>
 struct HeadGeo {
-  static_assert(kD == 64 || kD == 128, "compiled head dims");
-  static constexpr int kRowBytes = kD * 2;               // logical row
+  static_assert(kD == 64 || kD == 96 || kD == 128, "compiled head dims");
+  static constexpr int kLay = kD == 64 ? 64 : 128;       // width of the LDS layout (a 96-wide row lives in a 128-wide one)
+  static constexpr int kRowBytes = kLay * 2;             // logical row (in LDS)
   static constexpr int kKSteps = kD / 16;                // 16-wide k-steps of a contraction over d
   static constexpr int kDBlocks = kD / 32;               // 32-wide blocks of d (accumulator tiles)
-  static constexpr int kSwzRows = kD == 128 ? 16 : 32;   // logical rows after which the swizzle repeats:
+  static constexpr int kSwzRows = kLay == 128 ? 16 : 32; // logical rows after which the swizzle repeats:
                                                          // tile_off_d(r + kSwzRows, c) = tile_off_d(r, c) + kSwzRows * kRowBytes
 };
 template <int kD>
 __device__ __forceinline__ int tile_off_d(int row, int chunk) {
-  if (kD == 128) return row * 256 + ((chunk ^ swz(row)) << 4);
+  if (kD != 64) return row * 256 + ((chunk ^ swz(row)) << 4);
   const int prow = row >> 1, c = ((row & 1) << 3) | chunk;
   return prow * 256 + ((c ^ swz(prow)) << 4);
 }
@@ -110,7 +112,7 @@ template <int kD>
 __device__ __forceinline__ void dma_lane_src(int piece, int lane, int& row, int& chunk) {
   const int prow = 4 * piece + (lane >> 4);
   const int c = (lane & 15) ^ swz(prow);
-  if (kD == 128) {
+  if (kD != 64) {
     row = prow;
     chunk = c;
   } else {

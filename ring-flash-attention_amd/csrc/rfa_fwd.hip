@@ -80,7 +80,7 @@ constexpr int kFwdSub = kFwdKV / 32;        // 32-key sub-tiles per tile
 #define RFA_FWD_STAGES 2     // LDS ring depth: tile j+STAGES-1 is in flight (DMA) while tile j is computed
 #endif
 constexpr int kFwdStages = RFA_FWD_STAGES;
-template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * kD * 2; }   // K[stages] + V[stages]
+template <int kD> constexpr int fwd_smem() { return 2 * kFwdStages * kFwdKV * HeadGeo<kD>::kRowBytes; }   // K[stages] + V[stages]
 
 // kD: compiled head dim (128 or 64: half the MFMAs, half the LDS bytes per tile); kFullD: D == kD (LDS-DMA
 // staging, no conditional loads), otherwise D < kD is zero padded through the register staging path
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
   constexpr int kFwdTileBytes = kFwdKV * kRowBytes;          // 16 KiB (8 KiB at kD = 64)
   constexpr int kFwdShare = kFwdTileBytes / 1024 / kFwdWaves;   // 1 KiB DMA pieces (4 physical rows) per wave
-  constexpr int kChunks = kD / 8;                            // 16-byte chunks per logical row
+  constexpr int kChunks = Geo::kLay / 8;                     // 16-byte chunks per logical (LDS) row
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   constexpr int kRowsPerPass = kFwdThreads / kChunks;      // register path: one 16-byte chunk per thread and pass
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;
-  const bool sd_ok = kFullD || sc * 8 < p.D;
+  const bool sd_ok = (kFullD && kD == Geo::kLay) || sc * 8 < p.D;   // (kD = 96: the layout's chunks 12..15 are not part of the head)
   vec8<T> kreg[kFwdShare], vreg[kFwdShare];
   int voff_k[kFwdShare], voff_v[kFwdShare];
 #pragma unroll
@@ -540,6 +540,10 @@ static int launch_fwd_t(const FwdParams& p, hipStream_t stream) {
 template <typename T, bool kWin, bool kDrop>
 static int launch_fwd_d(const FwdParams& p, hipStream_t stream) {
   if (p.D == 128) return launch_fwd_t<T, 128, true, kWin, kDrop>(p, stream);
+  if constexpr (!kWin && !kDrop) {          // 64 < D <= 96: the 128-wide layout with three quarters of the MFMA work
+    if (p.D == 96) return launch_fwd_t<T, 96, true, kWin, kDrop>(p, stream);
+    if (p.D > 64 && p.D < 96) return launch_fwd_t<T, 96, false, kWin, kDrop>(p, stream);
+  }
   if (p.D > 64) return launch_fwd_t<T, 128, false, kWin, kDrop>(p, stream);
   if (p.D == 64) return launch_fwd_t<T, 64, true, kWin, kDrop>(p, stream);
   return launch_fwd_t<T, 64, false, kWin, kDrop>(p, stream);

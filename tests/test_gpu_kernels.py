@@ -733,6 +733,76 @@ def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
 
 
 # ------------------------------------------------------------------------------------------------------------
+# head dims 65 .. 96: kernel instances over the 128-wide LDS layout that run three of the four 32-column blocks of MFMA
+# work (csrc/rfa_common.hpp: HeadGeo<96>) — D == 96 with LDS-DMA staging, 64 < D < 96 zero padded through registers
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal,dtype", [
+    (2, 700, 700, 4, 2, 96, True, BF),               # GQA, batch, ragged tails, the LDS-DMA instance
+    (1, 512, 1300, 3, 3, 96, False, BF),             # rectangular, unmasked, odd head count (the last head's row ends the tensor)
+    (1, 1000, 488, 2, 1, 96, True, torch.float16),   # more queries than keys (rows without keys), fp16 MFMAs
+    (1, 640, 640, 2, 2, 80, True, BF),               # 64 < D < 96: register staging with zero fill, same instances
+    (2, 300, 520, 4, 4, 72, False, BF),
+    (1, 96, 4000, 2, 2, 96, True, BF),               # one query block against 63 key tiles
+])
+def test_head_dims_65_to_96_match_oracle(B, Sq, Sk, H, Hk, D, causal, dtype):
+    """forward (plain and merged into fp32 accumulators) and backward (plain and += outputs) of the three-block instances
+    against the CPU oracle; packed (cu_seqlens) input through the same instances"""
+    from ring_flash_attn.backend import get_backend, set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    g = torch.Generator().manual_seed(D + Sq)
+    q = torch.randn(B, Sq, H, D, generator=g).to(dtype)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(dtype)
+    do = torch.randn(B, Sq, H, D, generator=g).to(dtype)
+    ro, rl, rdq, rdk, rdv = _oracle_dense(q, k, v, do, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    scale = D ** -0.5
+    out = torch.empty_like(qd)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=causal, out=out, lse=lse)
+    _check("out", out, ro, 0, kind="out")
+    _check("lse", lse, rl, 0, kind="lse")
+    if not causal:                                   # the fused merge epilogue: two key halves into one accumulator
+        acc = torch.zeros(B, Sq, H, D, dtype=torch.float32, device=dev)
+        lacc = torch.empty(B, H, Sq, dtype=torch.float32, device=dev)
+        half = Sk // 2
+        be.fwd(qd, kd[:, :half], vd[:, :half], softmax_scale=scale, causal=False, out_acc=acc, lse_acc=lacc, acc_init=True)
+        be.fwd(qd, kd[:, half:], vd[:, half:], softmax_scale=scale, causal=False, out_acc=acc, lse_acc=lacc)
+        _check("out_acc", acc, ro, 0, kind="out")
+        _check("lse_acc", lacc, rl, 0, kind="lse")
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq=dq, dk=dk, dv=dv)
+    _grads_ok(f"D={D}", (dq, dk, dv), (rdq, rdk, rdv))
+    dqa = torch.full((B, Sq, H, D), 3.0, dtype=torch.float32, device=dev)
+    dka = torch.zeros((B, Sk, Hk, D), dtype=torch.float32, device=dev)
+    dva = torch.zeros_like(dka)
+    be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=scale, causal=causal, dq_acc=dqa, dk_acc=dka, dv_acc=dva)
+    _check("dq_acc", dqa - 3.0, rdq, 0, kind="grad")
+    _check("dk_acc", dka, rdk, 0, kind="grad")
+    _check("dv_acc", dva, rdv, 0, kind="grad")
+    if B == 2 and Sq == Sk:                          # the same rows as two packed sequences of different lengths
+        cu = torch.tensor([0, 300, 300 + Sq], dtype=torch.int32)
+        T = int(cu[-1])
+        qp, kp, vp, dop = (torch.cat([t[0, :300], t[1]], 0).contiguous() for t in (q, k, v, do))
+        po, pl, pdq, pdk, pdv = _oracle_varlen(qp, kp, vp, dop, cu, cu, causal)
+        qpd, kpd, vpd, dopd, cud = (t.to(dev) for t in (qp, kp, vp, dop, cu))
+        o2 = torch.empty_like(qpd)
+        l2 = torch.empty((H, T), dtype=torch.float32, device=dev)
+        be.fwd(qpd, kpd, vpd, softmax_scale=scale, causal=causal, cu_seqlens_q=cud, cu_seqlens_k=cud, max_seqlen_q=Sq,
+               max_seqlen_k=Sq, out=o2, lse=l2)
+        _check("varlen.out", o2, po, 0, kind="out")
+        d2 = torch.empty_like(l2)
+        be.bwd_preprocess(dopd, o2, d2, cu_seqlens_q=cud, max_seqlen_q=Sq)
+        g2 = [torch.empty_like(t) for t in (qpd, kpd, vpd)]
+        be.bwd(dopd, qpd, kpd, vpd, l2, d2, softmax_scale=scale, causal=causal, cu_seqlens_q=cud, cu_seqlens_k=cud,
+               max_seqlen_q=Sq, max_seqlen_k=Sq, dq=g2[0], dk=g2[1], dv=g2[2])
+        _grads_ok(f"varlen D={D}", g2, (pdq, pdk, pdv))
+
+
+# ------------------------------------------------------------------------------------------------------------
 # the 128-row (4-wave) forward form: picked by the library for grids that would leave the chip under-filled
 # (csrc/rfa_api.cpp: fewer than 384 workgroups of 256 rows); RFA_FWD_FORM=8x32 forces the 256-row form
 @pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal,dtype", [
