@@ -699,6 +699,8 @@ int main(int argc, char** argv) {
       {"noncausal rect", 1, 4, 4, 128, 333, 590, 0, {}, {}},
       {"d64", 1, 2, 1, 64, 257, 257, 1, {}, {}},
       {"d8 (llama3 test dim)", 1, 5, 5, 8, 529, 529, 1, {}, {}},
+      {"d96 gqa causal (three-block instances, LDS-DMA)", 2, 4, 2, 96, 515, 515, 1, {}, {}},
+      {"d80 rect noncausal (three-block instances, register staging)", 1, 3, 1, 80, 200, 456, 0, {}, {}},
       {"varlen ref fixture/8", 0, 5, 5, 128, 0, 0, 1, {0, 16, 156, 530}, {}},
       {"varlen noncausal", 0, 4, 2, 128, 0, 0, 0, {0, 120, 1248, 1500}, {}},
       {"varlen q!=k (llama3 style)", 0, 4, 2, 128, 0, 0, 1, {0, 100, 356}, {0, 300, 812}},
