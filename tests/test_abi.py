@@ -440,3 +440,41 @@ def test_wide_head_dim_kernels_fit_the_register_file(tmp_path):
     assert len(seen.get("fwd_big", [])) == 4 and len(seen.get("dq_big", [])) == 4 and len(seen.get("dkdv_big", [])) == 8, seen
     assert all(v <= 512 and s == 0 for v, s in seen["fwd_big"] + seen["dkdv_big"]), seen
     assert all(s <= 32 for _, s in seen["dq_big"]), seen
+
+
+def test_tuned_kernels_run_two_waves_per_simd_without_scratch(tmp_path):
+    """csrc/rfa_fwd.hip / rfa_bwd.hip / rfa_dqs.hip are built around TWO waves per SIMD: every instance (head dims 128, 96
+    and 64, full and padded, windows, dropout, the 128-row forward, both dK/dV forms with and without the dS spill) must stay
+    within 256 registers and off the scratch — the round-4 experiments that did not (the software-pipelined forward: Q
+    fragments in scratch, 3x slower) were correct and useless.  Also pins the instance sets the launchers dispatch to:
+    head dims 65 .. 96 have their own three-block instances of the three 7-GEMM kernels (bf16 and fp16)."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    found = {}
+    for f in ("rfa_fwd.hip", "rfa_bwd.hip", "rfa_dqs.hip"):
+        out = tmp_path / f
+        out.mkdir()
+        src = os.path.join(ROOT, "ring-flash-attention_amd", "csrc", f)
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", str(out / "x.o"),
+                            "-Wno-inline-asm", "-Wno-unused-result", "-save-temps=obj"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out / [g for g in os.listdir(out) if g.endswith("gfx950.s")][0]).read()
+        for name, priv, vgpr, spill in re.findall(
+                r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text):
+            found[name] = (int(priv), int(vgpr), int(spill))
+    kinds = {k: [n for n in found if k in n] for k in ("fwd_kernel", "dq_kernel", "dkdv_kernel", "dq_ds_kernel")}
+    assert all(len(v) >= 4 for v in kinds.values()), {k: len(v) for k, v in kinds.items()}
+    # (known exception, unchanged since round 2: the zero-PADDED 128-wide dK/dV instances with a window or dropout — head dims
+    #  97 .. 127, or 65 .. 127 with a window / dropout — hold their staging registers on top of a full file and keep one or two
+    #  values in scratch outside the MFMA blocks: 8 - 20 bytes)
+    def padded_special(n):
+        return "dkdv_kernel" in n and "Li128ELb0E" in n
+    bad = {n: v for n, v in found.items() if any(k in n for k in kinds) and
+           (v[1] > 256 or ((v[0] > 32 or v[2] > 4) if padded_special(n) else (v[0] != 0 or v[2] != 0)))}
+    assert not bad, bad
+    for k, per_dtype in (("fwd_kernel", 3), ("dq_kernel", 2), ("dkdv_kernel", 2)):      # (forward: + the 128-row form of D = 96)
+        n96 = [n for n in kinds[k] if "Li96E" in n]
+        assert len(n96) == 2 * per_dtype, (k, n96)
