@@ -36,12 +36,13 @@ def _single_rank(group) -> bool:
     return dist.get_world_size(group) == 1
 
 
-def _compilable(fn, lower):
+def _compilable(fn, lower, multi=None):
     """Public callable = `fn` (eager: the autograd Functions above, opaque to dynamo) except while dynamo is
     TRACING it on a single-rank group: then `lower(...)` expresses the call with the registered custom
     operators (_ops.py: rfa::attn_fwd / rfa::attn_bwd, fake kernels + autograd formula), so `torch.compile`
     captures the operator in its graph instead of breaking it (the reference runs its tests a second time under
-    torch.compile: test/test.sh:23-25)."""
+    torch.compile: test/test.sh:23-25).  `multi(...)`, where the schedule has one: the same for a multi-rank group —
+    the whole schedule as one operator per direction (_ops.py: rfa::sched_fwd / rfa::sched_bwd)."""
     import functools
 
     eager = _opaque(fn)
@@ -56,8 +57,13 @@ def _compilable(fn, lower):
             # `group` may be passed positionally: resolve it the way the call itself would
             bound = sig.bind(*args, **kwargs).arguments
             # (dropout draws a host-side seed per call: such calls run eagerly behind a graph break)
-            if _single_rank(bound.get("group", None)) and not bound.get("dropout_p", 0.0):
-                return lower(*args, **kwargs)
+            if not bound.get("dropout_p", 0.0):
+                if _single_rank(bound.get("group", None)):
+                    return lower(*args, **kwargs)
+                # several ranks: the whole schedule as one registered operator (_ops.py: rfa::sched_fwd / sched_bwd),
+                # where the schedule has one — windows raise over a multi-rank ring, llama3 keeps the graph break
+                if multi is not None and not has_window(bound.get("window_size", (-1, -1))):
+                    return multi(*args, **kwargs)
         return eager(*args, **kwargs)
 
     return public
@@ -316,9 +322,28 @@ def make_dense_api(fn, prefix, forward_impl=None, backward_impl=None, packed_tra
     def lower_qkv(qkv, *a, **kw):
         return lower(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], *a, **kw)
 
+    multi = multi_kv = multi_qkv = None
+    if forward_impl is not None:
+        from . import _ops
+
+        _ops.register_schedule(prefix, forward_impl, backward_impl)
+
+        def multi(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+                  deterministic=False, return_attn_probs=False, group=None):
+            _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=False)
+            assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
+            return _ops.multi_rank_attention(prefix, q, k, v, None, 0, softmax_scale, causal, return_attn_probs, group)
+
+        def multi_kv(q, kv, *a, **kw):
+            return multi(q, kv[:, :, 0], kv[:, :, 1], *a, **kw)
+
+        def multi_qkv(qkv, *a, **kw):
+            return multi(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], *a, **kw)
+
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return _compilable(func, lower), _compilable(kvpacked_func, lower_kv), _compilable(qkvpacked_func, lower_qkv)
+    return (_compilable(func, lower, multi), _compilable(kvpacked_func, lower_kv, multi_kv),
+            _compilable(qkvpacked_func, lower_qkv, multi_qkv))
 
 
 def make_varlen_api(fn, prefix, forward_impl=None, backward_impl=None):
@@ -370,6 +395,26 @@ def make_varlen_api(fn, prefix, forward_impl=None, backward_impl=None):
     def lower_qkv(qkv, *a, **kw):
         return lower(qkv[:, 0], qkv[:, 1], qkv[:, 2], *a, **kw)
 
+    multi = multi_kv = multi_qkv = None
+    if forward_impl is not None:
+        from . import _ops
+
+        _ops.register_schedule(prefix, forward_impl, backward_impl)
+
+        def multi(q, k, v, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, causal=False,
+                  window_size=(-1, -1), alibi_slopes=None, deterministic=False, return_attn_probs=False, group=None):
+            _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=False)
+            assert causal or not must_be_causal, f"{prefix} is meaningless for causal=False"
+            return _ops.multi_rank_attention(prefix, q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal,
+                                             return_attn_probs, group)
+
+        def multi_kv(q, kv, *a, **kw):
+            return multi(q, kv[:, 0], kv[:, 1], *a, **kw)
+
+        def multi_qkv(qkv, *a, **kw):
+            return multi(qkv[:, 0], qkv[:, 1], qkv[:, 2], *a, **kw)
+
     for f, suffix in ((func, "func"), (kvpacked_func, "kvpacked_func"), (qkvpacked_func, "qkvpacked_func")):
         f.__name__ = f.__qualname__ = f"{prefix}_{suffix}"
-    return _compilable(func, lower), _compilable(kvpacked_func, lower_kv), _compilable(qkvpacked_func, lower_qkv)
+    return (_compilable(func, lower, multi), _compilable(kvpacked_func, lower_kv, multi_kv),
+            _compilable(qkvpacked_func, lower_qkv, multi_qkv))

@@ -11,10 +11,23 @@ calls dynamo cannot trace, so they are registered as custom operators with fake 
 
 with an autograd formula linking them.  When a public function is traced by dynamo and the process
 group has a single rank (every schedule then IS one attention call), it lowers to these operators and
-the compiled graph contains them as opaque nodes — no graph break.  With more than one rank the
-schedules interleave kernels with RCCL traffic and stay behind `torch.compiler.disable` (graph break,
-eager execution, identical results).  Eager calls never come through here: they keep the autograd
-Functions of _api.py (packed gradients written into one buffer).
+the compiled graph contains them as opaque nodes — no graph break.
+
+With more than one rank a schedule interleaves kernels with RCCL traffic, which dynamo cannot trace either; the WHOLE
+schedule is then one operator (round 4):
+
+    rfa::sched_fwd(schedule, q, k, v, cu_seqlens?, max_seqlen, softmax_scale, causal, group_name) -> (out, lse)
+    rfa::sched_bwd(schedule, dout, q, k, v, out, lse, cu_seqlens?, max_seqlen, softmax_scale, causal, group_name)
+                                                                        -> (dq, dk, dv)
+
+`schedule` names a registered (forward, backward) pair — ring / zigzag / stripe and the two varlen forms — and
+`group_name` the process group (ProcessGroup.group_name, resolved inside the operator), so a `torch.compile`d caller
+captures a multi-rank call as one opaque node as well (`fullgraph=True` holds at world size 2, 4: tests/_ring_worker.py,
+RFA_TEST_COMPILE).  The operator runs the eager schedule — same kernels, same exchange, same order — minus the
+forward-to-backward hand-over of gathered K/V (an operator's backward sees only what it saved: it gathers again).
+llama3 (head groups, dropout, windows) and dropout calls stay behind `torch.compiler.disable`: a graph break around an
+eagerly executed schedule, identical results.  Eager calls never come through here: they keep the autograd Functions
+of _api.py (packed gradients written into one buffer, kept K/V).
 """
 from typing import Optional, Tuple
 
@@ -125,4 +138,101 @@ def single_device_attention(q, k, v, cu_seqlens, max_seqlen, softmax_scale, caus
         cu_seqlens = cu_seqlens.to(device=q.device, dtype=torch.int32).contiguous()
     out, lse = torch.ops.rfa.attn_fwd(q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal),
                                       int(window_size[0]), int(window_size[1]))
+    return (out, lse, None) if return_attn_probs else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multi-rank schedules as ONE operator each way
+_SCHEDULES = {}
+
+
+def register_schedule(name: str, forward_impl, backward_impl):
+    """_api.make_dense_api / make_varlen_api register their (forward, backward) schedule under the public prefix"""
+    _SCHEDULES[name] = (forward_impl, backward_impl)
+
+
+def has_schedule(name: str) -> bool:
+    return name in _SCHEDULES
+
+
+def group_name_of(group) -> str:
+    import torch.distributed as dist
+
+    return (group if group is not None else dist.group.WORLD).group_name
+
+
+def _group_of(name: str):
+    from torch.distributed import distributed_c10d as c10d
+
+    return c10d._resolve_process_group(name)
+
+
+def _lead(cu_seqlens, max_seqlen):
+    return () if cu_seqlens is None else (cu_seqlens, max_seqlen)
+
+
+@torch.library.custom_op("rfa::sched_fwd", mutates_args=())
+def sched_fwd(schedule: str, q: Tensor, k: Tensor, v: Tensor, cu_seqlens: Optional[Tensor], max_seqlen: int,
+              softmax_scale: float, causal: bool, group_name: str) -> Tuple[Tensor, Tensor]:
+    fwd, _ = _SCHEDULES[schedule]
+    out, lse = fwd(_group_of(group_name), q, k, v, *_lead(cu_seqlens, max_seqlen), softmax_scale=softmax_scale,
+                   dropout_p=0.0, causal=causal, window_size=(-1, -1), alibi_slopes=None, deterministic=False)
+    return out.contiguous(), lse.contiguous()
+
+
+@sched_fwd.register_fake
+def _sched_fwd_fake(schedule, q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, group_name):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty(_lse_shape(q, cu_seqlens is not None), dtype=torch.float32, device=q.device))
+
+
+@torch.library.custom_op("rfa::sched_bwd", mutates_args=())
+def sched_bwd(schedule: str, dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor,
+              cu_seqlens: Optional[Tensor], max_seqlen: int, softmax_scale: float, causal: bool,
+              group_name: str) -> Tuple[Tensor, Tensor, Tensor]:
+    _, bwd = _SCHEDULES[schedule]
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
+    dq, dk, dv = bwd(_group_of(group_name), dout, q, k, v, out, lse, *_lead(cu_seqlens, max_seqlen),
+                     softmax_scale=softmax_scale, dropout_p=0.0, causal=causal, window_size=(-1, -1),
+                     alibi_slopes=None, deterministic=False)
+    return dq.contiguous(), dk.contiguous(), dv.contiguous()
+
+
+@sched_bwd.register_fake
+def _sched_bwd_fake(schedule, dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale, causal, group_name):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty(k.shape, dtype=k.dtype, device=k.device),
+            torch.empty(v.shape, dtype=v.dtype, device=v.device))
+
+
+def _sched_setup_context(ctx, inputs, output):
+    schedule, q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, group_name = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, out, lse, cu_seqlens)
+    ctx.meta = (schedule, max_seqlen, softmax_scale, causal, group_name)
+
+
+def _sched_backward(ctx, dout, dlse):
+    q, k, v, out, lse, cu_seqlens = ctx.saved_tensors
+    schedule, max_seqlen, softmax_scale, causal, group_name = ctx.meta
+    dq, dk, dv = torch.ops.rfa.sched_bwd(schedule, dout, q, k, v, out, lse, cu_seqlens, max_seqlen, softmax_scale,
+                                         causal, group_name)
+    return None, dq, dk, dv, None, None, None, None, None
+
+
+torch.library.register_autograd("rfa::sched_fwd", _sched_backward, setup_context=_sched_setup_context)
+
+
+def multi_rank_attention(schedule, q, k, v, cu_seqlens, max_seqlen, softmax_scale, causal, return_attn_probs, group):
+    """a multi-rank call of a registered schedule as traceable operators; inputs normalised as the eager entry points do"""
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+    if cu_seqlens is not None:
+        if not torch.is_tensor(cu_seqlens):
+            cu_seqlens = torch.tensor(cu_seqlens, dtype=torch.int32)
+        cu_seqlens = cu_seqlens.to(device=q.device, dtype=torch.int32).contiguous()
+    out, lse = torch.ops.rfa.sched_fwd(schedule, q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal),
+                                       group_name_of(group))
     return (out, lse, None) if return_attn_probs else out

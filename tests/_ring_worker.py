@@ -90,18 +90,26 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
             from torch import _dynamo as dynamo
 
             dynamo.reset()
+            # one compiled caller per public function serves every case of the list (shapes, dtypes, argument counts differ):
+            # past dynamo's recompile limit a frame silently runs EAGERLY, i.e. the test would stop testing the compiled form
+            for lim in ("recompile_limit", "cache_size_limit", "accumulated_recompile_limit", "accumulated_cache_size_limit"):
+                if hasattr(dynamo.config, lim):
+                    setattr(dynamo.config, lim, 4096)
             eager_R, R = R, types.SimpleNamespace()
 
-            def compiled_caller(fn):
+            def compiled_caller(fn, fullgraph):
                 def caller(*a, **kw_):
                     a = tuple((t * 1 if torch.is_tensor(t) and t.is_floating_point() else t) for t in a)
                     res = fn(*a, **kw_)
                     return tuple((t + 0 if torch.is_tensor(t) else t) for t in res) if isinstance(res, tuple) else res + 0
-                return torch.compile(caller, backend="aot_eager")
+                return torch.compile(caller, backend="aot_eager", fullgraph=fullgraph)
 
+            # round 4: ring / zigzag / stripe and their varlen forms lower to ONE registered operator per direction at any
+            # world size (ring_flash_attn/_ops.py: rfa::sched_fwd / sched_bwd) — `fullgraph=True` turns any graph break into
+            # an error; the llama3 functions keep the graph break described above
             for name in dir(eager_R):
                 obj = getattr(eager_R, name)
-                setattr(R, name, compiled_caller(obj) if name.endswith("_func") else obj)
+                setattr(R, name, compiled_caller(obj, fullgraph="llama3" not in name) if name.endswith("_func") else obj)
         for n in names:
             c = MG.CASES[n]
             (q, k, v, do), extra = MG.shard(c, rank)
@@ -149,8 +157,15 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                            qe, ke, ve, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=c["stride"], local_k_slice=sl,
                            causal=True, **kw)}[kind]
                 qe, ke, ve = [t.detach().clone().requires_grad_(True) for t in (q, k, v)]
-                oe, le, _ = efn()
-                oe.backward(do)
+                # (the operator form of a multi-rank schedule has no forward-to-backward hand-over of gathered K/V: its
+                #  backward gathers again and runs the local block FIRST — the eager call without the hand-over — where
+                #  the eager default runs it last, beside the all-to-all: another fp32 summation order of dQ)
+                from ring_flash_attn import config as _cfg
+                import contextlib
+
+                with (_cfg.override(kv_keep=False) if kind == "zigzag" else contextlib.nullcontext()):
+                    oe, le, _ = efn()
+                    oe.backward(do)
                 for nm, a_, b_ in (("out", out, oe), ("lse", lse, le), ("dq", q.grad, qe.grad), ("dk", k.grad, ke.grad),
                                    ("dv", v.grad, ve.grad)):
                     if not torch.equal(a_.detach(), b_.detach()):
