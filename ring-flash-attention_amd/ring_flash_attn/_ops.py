@@ -25,8 +25,8 @@ schedule is then one operator (round 4):
 captures a multi-rank call as one opaque node as well (`fullgraph=True` holds at world size 2, 4: tests/_ring_worker.py,
 RFA_TEST_COMPILE).  The operator runs the eager schedule — same kernels, same exchange, same order — minus the
 forward-to-backward hand-over of gathered K/V (an operator's backward sees only what it saved: it gathers again).
-llama3 (head groups, dropout, windows) and dropout calls stay behind `torch.compiler.disable`: a graph break around an
-eagerly executed schedule, identical results.  Eager calls never come through here: they keep the autograd Functions
+llama3 has its own pair (rfa::llama3_fwd / rfa::llama3_bwd, at the end of this file).  Dropout calls (a host-side seed
+per call) stay behind `torch.compiler.disable`: a graph break around an eagerly executed schedule, identical results.  Eager calls never come through here: they keep the autograd Functions
 of _api.py (packed gradients written into one buffer, kept K/V).
 """
 from typing import Optional, Tuple
@@ -235,4 +235,89 @@ def multi_rank_attention(schedule, q, k, v, cu_seqlens, max_seqlen, softmax_scal
         cu_seqlens = cu_seqlens.to(device=q.device, dtype=torch.int32).contiguous()
     out, lse = torch.ops.rfa.sched_fwd(schedule, q, k, v, cu_seqlens, int(max_seqlen), float(softmax_scale), bool(causal),
                                        group_name_of(group))
+    return (out, lse, None) if return_attn_probs else out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# llama3 all-gather context parallelism as one operator each way (any world size; windows included, dropout not: it
+# draws a host-side seed per call).  local_k_slice travels as its (start, stop) pair.
+@torch.library.custom_op("rfa::llama3_fwd", mutates_args=())
+def llama3_fwd(q: Tensor, k: Tensor, v: Tensor, cu_seqlens_q: Tensor, cu_seqlens_k: Tensor, max_seqlen_q: int,
+               max_seqlen_k: int, heads_k_stride: int, k_start: int, k_stop: int, softmax_scale: float, causal: bool,
+               window_left: int, window_right: int, group_name: str) -> Tuple[Tensor, Tensor]:
+    from .llama3_flash_attn_varlen import llama3_flash_attn_varlen_forward
+
+    out, lse = llama3_flash_attn_varlen_forward(
+        _group_of(group_name), q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+        slice(k_start, k_stop), softmax_scale=softmax_scale, dropout_p=0.0, causal=causal,
+        window_size=(window_left, window_right), alibi_slopes=None, deterministic=False)
+    return out.contiguous(), lse.contiguous()
+
+
+@llama3_fwd.register_fake
+def _llama3_fwd_fake(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, k_start, k_stop,
+                     softmax_scale, causal, window_left, window_right, group_name):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty((q.shape[1], q.shape[0]), dtype=torch.float32, device=q.device))
+
+
+@torch.library.custom_op("rfa::llama3_bwd", mutates_args=())
+def llama3_bwd(dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor, cu_seqlens_q: Tensor,
+               cu_seqlens_k: Tensor, max_seqlen_q: int, max_seqlen_k: int, heads_k_stride: int, k_start: int, k_stop: int,
+               softmax_scale: float, causal: bool, window_left: int, window_right: int,
+               group_name: str) -> Tuple[Tensor, Tensor, Tensor]:
+    from .llama3_flash_attn_varlen import llama3_flash_attn_varlen_backward
+
+    if dout.stride(-1) != 1:
+        dout = dout.contiguous()
+    dq, dk, dv = llama3_flash_attn_varlen_backward(
+        _group_of(group_name), dout, q, k, v, out, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
+        heads_k_stride, slice(k_start, k_stop), softmax_scale=softmax_scale, dropout_p=0.0, causal=causal,
+        window_size=(window_left, window_right), alibi_slopes=None, deterministic=False)
+    return dq.contiguous(), dk.contiguous(), dv.contiguous()
+
+
+@llama3_bwd.register_fake
+def _llama3_bwd_fake(dout, q, k, v, out, lse, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+                     k_start, k_stop, softmax_scale, causal, window_left, window_right, group_name):
+    return (torch.empty(q.shape, dtype=q.dtype, device=q.device),
+            torch.empty(k.shape, dtype=k.dtype, device=k.device),
+            torch.empty(v.shape, dtype=v.dtype, device=v.device))
+
+
+def _llama3_setup_context(ctx, inputs, output):
+    (q, k, v, cu_q, cu_k, max_q, max_k, stride, k_start, k_stop, softmax_scale, causal, wl, wr, group_name) = inputs
+    out, lse = output
+    ctx.save_for_backward(q, k, v, out, lse, cu_q, cu_k)
+    ctx.meta = (max_q, max_k, stride, k_start, k_stop, softmax_scale, causal, wl, wr, group_name)
+
+
+def _llama3_backward(ctx, dout, dlse):
+    q, k, v, out, lse, cu_q, cu_k = ctx.saved_tensors
+    dq, dk, dv = torch.ops.rfa.llama3_bwd(dout, q, k, v, out, lse, cu_q, cu_k, *ctx.meta)
+    return (dq, dk, dv) + (None,) * 12
+
+
+torch.library.register_autograd("rfa::llama3_fwd", _llama3_backward, setup_context=_llama3_setup_context)
+
+
+def llama3_attention(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+                     softmax_scale, causal, window_size, return_attn_probs, group):
+    """llama3_flash_attn_varlen_func as traceable operators (inputs normalised as the eager entry point does)"""
+    if softmax_scale is None:
+        softmax_scale = q.shape[-1] ** (-0.5)
+    q, k, v = (t if t.is_contiguous() else t.contiguous() for t in (q, k, v))
+
+    def cu(c):
+        if not torch.is_tensor(c):
+            c = torch.tensor(c, dtype=torch.int32)
+        return c.to(device=q.device, dtype=torch.int32).contiguous()
+
+    if local_k_slice.step not in (None, 1):
+        raise ValueError("local_k_slice must be a contiguous slice")
+    k_start = int(local_k_slice.start or 0)
+    k_stop = int(local_k_slice.stop) if local_k_slice.stop is not None else (1 << 62)      # (open end)
+    out, lse = torch.ops.rfa.llama3_fwd(q, k, v, cu(cu_seqlens_q), cu(cu_seqlens_k), int(max_seqlen_q), int(max_seqlen_k),
+                                        int(heads_k_stride), k_start, k_stop, float(softmax_scale), bool(causal),
+                                        int(window_size[0]), int(window_size[1]), group_name_of(group))
     return (out, lse, None) if return_attn_probs else out

@@ -381,7 +381,43 @@ def _make_llama3_api():
     func.__name__ = func.__qualname__ = "llama3_flash_attn_varlen_func"
     kvpacked_func.__name__ = kvpacked_func.__qualname__ = "llama3_flash_attn_varlen_kvpacked_func"
     qkvpacked_func.__name__ = qkvpacked_func.__qualname__ = "llama3_flash_attn_varlen_qkvpacked_func"
-    return _opaque(func), _opaque(kvpacked_func), _opaque(qkvpacked_func)
+
+    # while dynamo TRACES a caller, a call without dropout is expressed with the registered operators rfa::llama3_fwd /
+    # rfa::llama3_bwd (_ops.py: the whole schedule — head-group all-gathers, kernels, the reduce-scatter of dK/dV — as one
+    # opaque node per direction, any world size), so the compiled graph has no break; eager calls keep the autograd
+    # Functions above (packed gradients written into one buffer)
+    def lower(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride, local_k_slice,
+              dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1), alibi_slopes=None,
+              deterministic=False, return_attn_probs=False, group=None):
+        from ._ops import llama3_attention
+
+        _check_unsupported(dropout_p, window_size, alibi_slopes, windows_ok=True)
+        return llama3_attention(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, heads_k_stride,
+                                local_k_slice, softmax_scale, causal, window_size, return_attn_probs, group)
+
+    def lower_kv(q, kv, *a, **kw):
+        return lower(q, kv[:, 0], kv[:, 1], *a, **kw)
+
+    def lower_qkv(qkv, *a, **kw):
+        return lower(qkv[:, 0], qkv[:, 1], qkv[:, 2], *a, **kw)
+
+    def compilable(fn, low):
+        import functools
+        import inspect
+
+        eager, sig = _opaque(fn), inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def public(*args, **kwargs):
+            if torch.compiler.is_compiling():
+                bound = sig.bind(*args, **kwargs).arguments
+                if not bound.get("dropout_p", 0.0) and isinstance(bound.get("local_k_slice"), slice):
+                    return low(*args, **kwargs)
+            return eager(*args, **kwargs)
+
+        return public
+
+    return compilable(func, lower), compilable(kvpacked_func, lower_kv), compilable(qkvpacked_func, lower_qkv)
 
 
 (

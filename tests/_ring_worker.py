@@ -104,12 +104,12 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                     return tuple((t + 0 if torch.is_tensor(t) else t) for t in res) if isinstance(res, tuple) else res + 0
                 return torch.compile(caller, backend="aot_eager", fullgraph=fullgraph)
 
-            # round 4: ring / zigzag / stripe and their varlen forms lower to ONE registered operator per direction at any
-            # world size (ring_flash_attn/_ops.py: rfa::sched_fwd / sched_bwd) — `fullgraph=True` turns any graph break into
-            # an error; the llama3 functions keep the graph break described above
+            # round 4: every schedule lowers to ONE registered operator per direction at any world size
+            # (ring_flash_attn/_ops.py: rfa::sched_fwd / sched_bwd, rfa::llama3_fwd / llama3_bwd) —
+            # `fullgraph=True` turns any graph break into an error
             for name in dir(eager_R):
                 obj = getattr(eager_R, name)
-                setattr(R, name, compiled_caller(obj, fullgraph="llama3" not in name) if name.endswith("_func") else obj)
+                setattr(R, name, compiled_caller(obj, fullgraph=True) if name.endswith("_func") else obj)
         for n in names:
             c = MG.CASES[n]
             (q, k, v, do), extra = MG.shard(c, rank)
