@@ -221,7 +221,9 @@ def test_config3_zigzag_w4_gqa_reduced():
 def test_config5_hf_adapter_qwen3(W, layers, cu):
     """llama3_flash_attn_varlen_func through the HF adapter on a random-init Qwen3-0.6B layer stack
     (hidden 1024, 16 q / 8 kv heads, head_dim 128, intermediate 3072; vocabulary cut to 4096 and 4 of the
-    28 layers so that 8 model replicas + the eager references share one GPU), heads_k_stride 1, packed
+    28 layers so that 8 model replicas + the eager references share one GPU: the fp32 eager reference keeps the attention
+    probabilities of its three sequences for the backward — 3000² + 6000² + 7384² scores x 16 heads x 4 bytes = 6.4 GB per
+    layer and saved tensor, i.e. all 28 layers would need more than the GPU's 288 GB), heads_k_stride 1, packed
     sequences deliberately not rank aligned (SURVEY §8d cfg 5)."""
     import _adapter_worker as AW
     from conftest import free_port
