@@ -7,7 +7,8 @@ seed 42+rank, causal; the data IS the local zigzag shard, total sequence = 8192 
 A "step" = one forward + one backward of that operator on every rank (grad reset each step).
 
     python bench.py --gpus 1 --steps K --warmup W                      # single GPU
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      # launches its own N ranks (torch.distributed.run)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   # or started as ranks
 
 Prints ONE JSON line (rank 0).  `value` = iterations/s of the whole job (max time over ranks).
 At every N the line carries
@@ -496,6 +497,26 @@ def comm_bytes_per_iter(mode, wire_fp32, world, hk):
     return (world - 1) * m + (world - 1) * contrib
 
 
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n):
+    """re-run this script with the same arguments as `n` ranks of one node under torch.distributed.run; returns the
+    launcher's exit status (non-zero when any rank failed).  RFA_BENCH_MASTER_PORT pins the rendezvous port."""
+    port = os.environ.get("RFA_BENCH_MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -528,9 +549,22 @@ def main():
     if args.wire:
         os.environ["RFA_DKV_WIRE"] = args.wire
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N` (the driver's command line): launch the N ranks ourselves, the
+        # way the reference's benchmark is started (`torchrun --nproc_per_node N`, /root/reference/README.md:135-147) —
+        # one process per GPU on this node, rendezvous on 127.0.0.1 and a free port.  The children inherit this
+        # process's stdout, so the contract's ONE JSON line (rank 0) still is the only thing on it.
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} visible GPU(s)")
+        raise SystemExit(launch_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; start it as "
+                         f"`python bench.py --gpus {args.gpus}` (it launches its own ranks) or under "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the operator has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -556,7 +590,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=0, world_size=1)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import ring_flash_attn as R
     from ring_flash_attn import config as rfa_config

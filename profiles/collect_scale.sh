@@ -1,7 +1,7 @@
 #!/bin/bash
 # north_star's multi-GPU evidence in ONE command, for whoever has an 8-GPU MI355X node (the development boxes have one
-# GPU; nothing here has run with N > 1):
-#     bash profiles/collect_scale.sh [N=8] [TAG=r04]
+# GPU; nothing here has run with N > 1 — round 5 ran it end to end at N = 1: profiles/r05_collect_scale_n1.txt):
+#     bash profiles/collect_scale.sh [N=8] [TAG=r05]          (N=1: a one-GPU rehearsal on a forced one-rank RCCL group)
 #   1. bench.py at N (RCCL over xGMI): the JSON line with `comm` — exchange form, the library's autotune record (ms per
 #      form, max over ranks), bytes per rank, compute_only_ms / exposed_ms — `roofline` and `cpu_baseline`
 #   2. tools/xgmi_probe.py: point-to-point GB/s per peer (one xGMI link each), all-gather / all-to-all / neighbour-hop
@@ -14,19 +14,32 @@
 # Output: gpurun_out/scale/<TAG>_*.json|txt — copy into profiles/.
 set -u
 N=${1:-8}
-TAG=${2:-r04}
+TAG=${2:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=$R/gpurun_out/scale
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-RUN="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1"
-$RUN --master-port 29611 $R/bench.py --gpus $N --steps 50 --warmup 10 > $OUT/${TAG}_bench_n${N}.json 2> $OUT/${TAG}_bench_n${N}.err
+if [ "$N" = "1" ]; then
+  # one-GPU rehearsal of this script (profiles/r05_collect_scale_n1.txt): a ONE-rank RCCL group with the schedule
+  # forced onto its multi-step path (RFA_BENCH_FORCE_RCCL: every collective, the side stream and bench.py's N > 1
+  # branches run; the numbers are not measurements of anything)
+  export RFA_BENCH_FORCE_RCCL=1
+  CPUB="--cpu-baseline-budget-s 10"      # (the rehearsal does not need a long CPU sample)
+  PROBE="python $R/tools/xgmi_probe.py"
+else
+  CPUB=""
+  PROBE="python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29613 $R/tools/xgmi_probe.py"
+fi
+# bench.py launches its own N ranks (torch.distributed.run on 127.0.0.1 and a free port): the driver's command line
+BENCH="python $R/bench.py --gpus $N"
+$BENCH --steps 50 --warmup 10 $CPUB > $OUT/${TAG}_bench_n${N}.json 2> $OUT/${TAG}_bench_n${N}.err
 for mode in gather ring; do
-  $RUN --master-port 29612 $R/bench.py --gpus $N --steps 50 --warmup 10 --exchange $mode --no-cpu-baseline > $OUT/${TAG}_bench_n${N}_${mode}.json 2>> $OUT/${TAG}_bench_n${N}.err
+  $BENCH --steps 50 --warmup 10 --exchange $mode --no-cpu-baseline > $OUT/${TAG}_bench_n${N}_${mode}.json 2>> $OUT/${TAG}_bench_n${N}.err
 done
-$RUN --master-port 29613 $R/tools/xgmi_probe.py > $OUT/${TAG}_xgmi_probe_n${N}.json 2> $OUT/${TAG}_xgmi_probe_n${N}.err
-rocprofv3 --kernel-trace --rccl-trace --hip-trace -d $OUT/trace -o trace -- $RUN --master-port 29614 $R/bench.py --gpus $N --steps 6 --warmup 2 --no-cpu-baseline --no-breakdown > $OUT/trace.log 2>&1
+$PROBE > $OUT/${TAG}_xgmi_probe_n${N}.json 2> $OUT/${TAG}_xgmi_probe_n${N}.err
+rm -rf $OUT/trace
+rocprofv3 --kernel-trace --rccl-trace --hip-trace -d $OUT/trace -o trace -- $BENCH --steps 6 --warmup 2 --no-cpu-baseline --no-breakdown > $OUT/trace.log 2>&1
 cd $R
 python profiles/summarize_overlap.py $OUT/trace > $OUT/${TAG}_overlap_n${N}.txt 2>&1
 python - <<PY

@@ -113,24 +113,46 @@ def _keep_list(ctx, forward_impl):
 
 
 class _KeepList(list):
-    """the tensors a forward hands to its backward, plus the reservation they hold in the process-wide budget of kept
-    bytes (config.kept_budget): released when the backward has run, or with the autograd node"""
+    """the tensors a forward hands to its backward, the reservation they hold in the process-wide budget of kept bytes
+    (config.kept_budget) and the group's agreement that EVERY rank kept (utils.Agreement; None: nothing was asked)"""
     token = None
+    agreed = None
 
 
 def _hold_kept(ctx, keep):
-    ctx.kept_token = keep.token if keep else None
+    ctx.kept_token = keep.token if keep is not None else None
+    ctx.kept_agreed = keep.agreed if keep is not None else None
 
 
 def _release_kept(ctx):
+    """The reservation returns when the kept buffers are gone: with the backward when the graph is not retained, else
+    with the graph (Token.__del__).  Whether this backward retains the graph is not visible from inside it, so the test
+    runs as an engine callback at the END of the backward pass: by then a non-retained node has dropped its saved tensors
+    (reading them raises), a retained one still has them and keeps its reservation."""
     tok = getattr(ctx, "kept_token", None)
-    if tok is not None:
+    if tok is None:
+        return
+
+    def after_backward():
+        try:
+            ctx.saved_tensors
+        except RuntimeError:
+            tok.release()
+
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(after_backward)
+    except Exception:                # (not inside an engine run: a direct call of the backward in a test)
         tok.release()
 
 
 def _split_kept(ctx, more):
     n = getattr(ctx, "n_lead_t", len(more))
     tensors_lead, kept = more[:n], more[n:]
+    agreed = getattr(ctx, "kept_agreed", None)
+    if agreed is not None and not agreed.resolve():
+        # some rank could not keep its gathered K/V: EVERY rank gathers again (a rank deciding alone would leave the
+        # others in a collective it does not join); this rank's buffers are simply not used
+        kept = ()
     return tensors_lead, ({"kept": tuple(kept)} if kept else {})
 
 

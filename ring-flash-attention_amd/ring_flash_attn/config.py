@@ -14,7 +14,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | zigzag_varlen_exchange    | RFA_ZIGZAG_VARLEN_EXCHANGE      | ring    | packed zigzag exchange form: ring / gather |
 | dkv_wire_fp32             | RFA_DKV_WIRE                    | io      | gather form: dK/dV contributions travel in the io dtype (io) or fp32 |
 | gather_max_bytes          | RFA_GATHER_MAX_BYTES            | 4 GiB   | auto without a measurement: gather while its O(S_total) scratch stays below |
-| autotune                  | RFA_AUTOTUNE                    | 1       | auto: the first multi-rank call per (group, shapes) MEASURES both forms once (tuning.py) |
+| autotune                  | RFA_AUTOTUNE                    | 0       | auto: 1 = the first multi-rank call per (group, shapes) MEASURES both forms itself (tuning.py); default: only explicit tuning.autotune_zigzag_exchange calls (bench.py's warm-up) measure |
 | kv_keep                   | RFA_ZIGZAG_KV_KEEP              | 1       | gather form: keep the gathered K/V of a forward for its backward |
 | kv_keep_bytes             | RFA_ZIGZAG_KV_KEEP_BYTES        | 4 GiB   | ... unless one call's gathered K/V exceed this |
 | kv_keep_total_bytes       | RFA_ZIGZAG_KV_KEEP_TOTAL_BYTES  | 4 GiB   | ... or all live kept buffers of the process together would (L layers x W x (K,V)) |
@@ -77,7 +77,7 @@ class Config:
     zigzag_varlen_exchange: str = "ring"
     dkv_wire_fp32: bool = False
     gather_max_bytes: int = 4 * _GiB
-    autotune: bool = True
+    autotune: bool = False
     kv_keep: bool = True
     kv_keep_bytes: int = 4 * _GiB
     kv_keep_total_bytes: int = 4 * _GiB

@@ -30,6 +30,8 @@ from . import config
 _LOCK = threading.Lock()
 _TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
 _REPORTS = {}        # same key -> the measurement (for bench.py / logs)
+_AGREED = set()      # (group instance, key): the group has established that every rank holds the SAME record (or none)
+_CODES = {None: 0, "gather": 1, "ring": 2}
 
 
 def _group_key(group):
@@ -44,14 +46,71 @@ def _group_key(group):
         return ("group", id(group))
 
 
+def _group_instance(group):
+    """identity of this INSTANCE of the group (a group re-created after a restart of some ranks agrees again)"""
+    try:
+        g = dist.group.WORLD if group is None else group
+        return getattr(g, "group_name", None) or id(g)
+    except Exception:
+        return id(group)
+
+
 def _key(world, q_shape, k_shape, dtype, group=None):
     B, S, H, D = q_shape
     return (_group_key(group), int(world), int(B), int(S), int(H), int(k_shape[2]), int(D), str(dtype))
 
 
 def lookup(q_shape, k_shape, dtype, world, group=None):
-    """the recorded exchange form for this problem on this group, or None"""
+    """the recorded exchange form for this problem on this group, or None — THIS rank's record; the schedules use
+    `agreed_lookup`"""
     return _TUNED.get(_key(world, q_shape, k_shape, dtype, group))
+
+
+def record(q_shape, k_shape, dtype, world, form, group=None):
+    """install a record by hand (a tuning file, a test).  It decides a call only after `agreed_lookup` has established
+    that every rank of the group holds the same one."""
+    if form not in ("gather", "ring"):
+        raise ValueError(f"exchange form must be gather or ring, got {form!r}")
+    key = _key(world, q_shape, k_shape, dtype, group)
+    with _LOCK:
+        _TUNED[key] = form
+        _AGREED.discard((_group_instance(group), key))
+
+
+def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
+    """The record every rank may act on.  A record is a rank-local fact (a tuning file read by some ranks, a process that
+    joined later, a measurement that only part of the group took), and ranks that disagree about the exchange form post
+    different collectives — so the FIRST use of a (group, shapes) pair in a process reduces the local record's code over
+    the group (one MIN + MAX all-reduce of two integers, host-synchronous, once): all ranks hold the same record -> it is
+    used; anything else (some without a record, different records) -> every rank forgets its own and the caller falls
+    through to a measurement or the shape rule, which all ranks take alike.  Records written by
+    `autotune_zigzag_exchange` are agreed by construction (it is a collective).  Not under stream capture (the result
+    could not be read back): there only an already agreed record is used."""
+    from . import utils
+
+    key = _key(world, q_shape, k_shape, dtype, group)
+    inst = (_group_instance(group), key)
+    if inst in _AGREED:
+        return _TUNED.get(key)
+    if utils._LOOPBACK is not None or world < 2:
+        return _TUNED.get(key)
+    if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return None
+    code = _CODES[_TUNED.get(key)]
+    on_host = dist.get_backend(group) == "gloo" or device.type != "cuda"
+    t = torch.tensor([code, -code], dtype=torch.int32, device="cpu" if on_host else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    with _LOCK:
+        if hi != lo or hi == 0:
+            if code and config.get().tuning_log:
+                import sys
+
+                sys.stderr.write(f"ring_flash_attn: exchange record {key} is not shared by every rank of the group: ignored\n")
+            _TUNED.pop(key, None)
+            _REPORTS.pop(key, None)
+        _AGREED.add(inst)
+    return _TUNED.get(key)
 
 
 def report(q_shape, k_shape, dtype, world, group=None):
@@ -61,22 +120,41 @@ def report(q_shape, k_shape, dtype, world, group=None):
 def can_measure(group, q) -> bool:
     """the library measures by itself only where the measurement means something and cannot disturb the caller: device
     tensors on an RCCL group of several ranks (gloo groups are the CPU / shared-GPU test paths), no exchange loopback
-    installed, outside stream capture and outside dynamo tracing"""
+    installed, outside stream capture, dynamo tracing and inference mode (the scratch tensors of the measurement would
+    be inference tensors, which autograd refuses to save: ADVICE r4)"""
     from . import utils
 
     if utils._LOOPBACK is not None or not q.is_cuda:
         return False
     if dist.get_backend(group) == "gloo" or dist.get_world_size(group) < 2:
         return False
-    if torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing():
+    if torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing() or torch.is_inference_mode_enabled():
         return False
     return True
+
+
+_FAILED = set()      # keys whose in-call measurement failed (on every rank: the verdict is reduced): not tried again
+
+
+def measure_in_call(group, q, k, v):
+    """the implicit path of `exchange_mode` (config.autotune, opt-in): never raises — a measurement that fails (every form
+    disqualified, on all ranks alike) leaves the shape rule in charge, and is not repeated"""
+    key = _key(dist.get_world_size(group), q.shape, k.shape, q.dtype, group)
+    if key in _FAILED:
+        return None
+    try:
+        return autotune_zigzag_exchange(group, q, k, v)["chosen"]
+    except RuntimeError:
+        _FAILED.add(key)
+        return None
 
 
 def clear():
     with _LOCK:
         _TUNED.clear()
         _REPORTS.clear()
+        _AGREED.clear()
+        _FAILED.clear()
 
 
 def _sync(dev):
@@ -102,10 +180,16 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     if key in _TUNED:
         return _REPORTS[key]
     dev = q.device
-    qs = torch.randn(q.shape, device=dev, dtype=torch.float32).to(q.dtype).requires_grad_(True)
-    ks = torch.randn(k.shape, device=dev, dtype=torch.float32).to(k.dtype).requires_grad_(True)
-    vs = torch.randn(v.shape, device=dev, dtype=torch.float32).to(v.dtype).requires_grad_(True)
-    do = torch.randn(q.shape, device=dev, dtype=torch.float32).to(q.dtype)
+    # scratch data from a PRIVATE generator: the caller's default RNG stream must not depend on whether, or in which
+    # order, shapes were measured
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x5EED)
+
+    def scratch(shape, dtype):
+        return torch.randn(tuple(shape), device=dev, dtype=torch.float32, generator=gen).to(dtype)
+
+    qs, ks, vs = (scratch(t.shape, t.dtype).requires_grad_(True) for t in (q, k, v))
+    do = scratch(q.shape, q.dtype)
     ms, failed = {}, {}
     for mode in modes:
         with config.override(zigzag_exchange=mode), torch.enable_grad():
@@ -141,6 +225,7 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     with _LOCK:
         _TUNED[key] = chosen
         _REPORTS[key] = rep
+        _AGREED.add((_group_instance(group), key))       # a collective measurement: every rank recorded this winner
     if config.get().tuning_log and dist.get_rank(group) == 0:
         import sys
 

@@ -317,6 +317,44 @@ def reduce_scatter_async(output: torch.Tensor, input_: torch.Tensor, group=None)
     return _post(group, input_, lambda: dist.reduce_scatter_tensor(output, input_, group=group, async_op=True))
 
 
+class Agreement:
+    """Group-wide AND of a rank-local boolean — the way a schedule turns a RANK-LOCAL fact (this rank's budget of kept
+    bytes had room; this rank holds a tuning record) into a decision every rank takes alike.  The sequence of collectives
+    a schedule posts must be a function of group-consistent state only: a rank that decides on its own whether to post
+    an all-gather leaves its peers inside a collective it never joins.
+
+    Posting does not stall the host: on an RCCL group the flag is reduced (MIN) under the side stream and copied to pinned
+    host memory behind an event; `resolve()` — called where the decision is needed, for a forward's flag that is its
+    backward, long after the transfer — waits for that event only.  gloo groups (CPU tensors; the shared-GPU test
+    path) reduce on the host at once."""
+
+    def __init__(self, process_group, flag: bool, device: torch.device):
+        self._value, self._event, self._host, self._dev = None, None, None, None
+        if _LOOPBACK is not None:
+            self._value = bool(flag)
+            return
+        if device.type == "cuda" and dist.get_backend(process_group) != "gloo":
+            side = comm_stream(device)
+            with torch.cuda.stream(side):
+                self._dev = torch.full((1,), int(bool(flag)), dtype=torch.int32, device=device)
+                dist.all_reduce(self._dev, op=dist.ReduceOp.MIN, group=process_group, async_op=True).wait()
+                self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                self._host.copy_(self._dev, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(side)
+        else:
+            t = torch.tensor([int(bool(flag))], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+            self._value = bool(t.item())
+
+    def resolve(self) -> bool:
+        if self._value is None:
+            self._event.synchronize()
+            self._value = bool(self._host.item())
+            self._event = self._host = self._dev = None
+        return self._value
+
+
 def reduce_scatter(output: torch.Tensor, input_: torch.Tensor, group=None):
     reduce_scatter_async(output, input_, group).wait()
 

@@ -45,7 +45,7 @@ import torch
 
 from . import _C, config
 from .backend import get_backend
-from .utils import AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
+from .utils import Agreement, AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 from ._common import packed_pair, dropout_arg
 
@@ -61,20 +61,24 @@ def _wire_fp32() -> bool:
 
 def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None, group=None, v: torch.Tensor = None) -> str:
     """config.zigzag_exchange (RFA_ZIGZAG_EXCHANGE) = gather | ring forces a form.  auto (default): the form a
-    MEASUREMENT on this group recorded for these shapes — taken by the library itself on the first multi-rank call of a
-    (group, shapes) pair on an RCCL group (tuning.autotune_zigzag_exchange: fwd + bwd a few times in each form on
-    scratch tensors, max over ranks, so every rank records the same winner; config.autotune / RFA_AUTOTUNE=0 switches
-    it off) — else, nothing measured or measurable, gather while its O(S_total) scratch stays below
-    config.gather_max_bytes, ring beyond: that rule reads shapes only, so every rank decides alike."""
+    MEASUREMENT on this group recorded for these shapes (tuning.autotune_zigzag_exchange — a collective: fwd + bwd a few
+    times in each form on scratch tensors, max over ranks, so every rank records the same winner; bench.py runs it in its
+    warm-up, a training script may call it once per shape; config.autotune / RFA_AUTOTUNE=1 lets the library take it
+    inside the first multi-rank call of a (group, shapes) pair — opt-in since round 5: it costs 2 forms x 4 fwd + bwd at
+    the caller's peak memory) — else, nothing measured or measurable, gather while its O(S_total) scratch stays below
+    config.gather_max_bytes, ring beyond.  Every input of the decision is group-consistent: the configuration, the
+    shapes, and a record only after tuning.agreed_lookup established that all ranks hold the same one."""
     cfg = config.get()
     mode = cfg.zigzag_exchange
     if mode == "auto":
         if q is not None:
             from . import tuning
 
-            tuned = tuning.lookup(q.shape, k.shape, q.dtype, world, group)
+            # (a record counts only once the group has established that every rank holds the same one: ranks that
+            #  disagree about the form post different collectives)
+            tuned = tuning.agreed_lookup(q.shape, k.shape, q.dtype, world, group, q.device)
             if tuned is None and v is not None and cfg.autotune and tuning.can_measure(group, q):
-                tuned = tuning.autotune_zigzag_exchange(group, q, k, v)["chosen"]
+                tuned = tuning.measure_in_call(group, q, k, v)
             if tuned is not None:
                 return tuned
         mode = "gather" if gather_scratch_bytes(k, world, cfg.dkv_wire_fp32) <= cfg.gather_max_bytes else "ring"
@@ -94,13 +98,22 @@ def exchange_mode(k: torch.Tensor, world: int, q: torch.Tensor = None, group=Non
 # where the reference saves only the local k / v), keeps nothing: its backward gathers again and keeps the
 # local-block-first order.  The reservation (config.kept_budget) is released when the backward has run or the graph
 # is freed.
-def _try_keep(keep, bufs):
+def _try_keep(keep, bufs, process_group):
+    """Whether THIS rank has room is a rank-local fact (config.kept_budget counts the live kept bytes of the process, and
+    graph lifetimes may differ between ranks: an output held for logging on rank 0 only, garbage-collection timing) — but
+    the backward's collective sequence depends on it (kept: no second all-gather).  So every rank that could keep posts
+    its flag into ONE tiny all-reduce (utils.Agreement, beside the all-gather on the side stream, no host stall) and the
+    backward uses the kept buffers only when EVERY rank kept (_api._split_kept resolves the flag); otherwise all ranks
+    gather again, the ones that did keep drop their buffers."""
     if keep is None:
         return
+    if bufs[0].is_cuda and torch.cuda.is_current_stream_capturing():
+        return                      # (the flag cannot be read back inside a capture; every rank captures alike)
     token = config.kept_budget.try_reserve(sum(b_.numel() * b_.element_size() for b_ in bufs))
     if token is not None:
         keep.extend(bufs)
         keep.token = token
+    keep.agreed = Agreement(process_group, token is not None, bufs[0].device)
 
 
 def _kv_views(bufs, k, world):
@@ -169,7 +182,7 @@ def zigzag_ring_flash_attn_forward(
         be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
         gather.wait()
-        _try_keep(keep, bufs)
+        _try_keep(keep, bufs, process_group)
         for step in range(1, comm.world_size):
             src = (comm.rank - step) % comm.world_size
             ks, vs = k_all[src], v_all[src]
