@@ -18,7 +18,7 @@ At every N the line carries
                  rank's step-0 (local causal) block on its own at N > 1 — the same launch at every world size;
   * `comm`       (N > 1) exchange form, bytes per rank per iteration, and `exposed_ms` = measured step minus
                  the same rank-local kernel sequence with the exchange looped back to local buffers
-                 (ring_flash_attn.utils.set_loopback), max over ranks;
+                 (ring_flash_attn._testing.set_loopback), max over ranks;
   * `cpu_baseline` the CPU path on a bounded sample of the same workload on this box's host cores: N = 1 the oracle's
                  forward / backward ("port"); N > 1 the zigzag schedule over N gloo CPU processes with the oracle
                  underneath (oracle/cpu_ring_baseline.py: the unmodified reference schedule where /root/reference
@@ -191,7 +191,7 @@ class InStepTimer:
     out up to 8 % longer than rocprofv3's kernel trace of the same run), each instrumented step brackets ONE launch
     kind only, in rotation (fwd / bwd_preprocess / dK/dV / dQ / reduce / the side kernels): before and after the
     backend call, or — inside rfa_bwd — through rfa_bwd_args.prof_events, of which only the two needed entries are
-    given.  Events are created before the steps.  Installed through ring_flash_attn.backend.set_backend for a few
+    given.  Events are created before the steps.  Installed through ring_flash_attn._testing.set_backend for a few
     extra steps after the timed region; the timed region itself runs the plain backend."""
 
     KINDS = ("fwd", "bwd_preprocess", "bwd_first", "bwd_second", "bwd_reduce", "side", "empty")
@@ -444,7 +444,7 @@ def cpu_baseline_ring(world, hk, budget_s, fwd_only=False):
         for r in range(world):
             env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port), OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-            for k_ in ("RFA_ZIGZAG_EXCHANGE", "RFA_TEST_FORCE_STEPS", "RFA_BENCH_FORCE_RCCL", "TORCHELASTIC_RUN_ID"):
+            for k_ in ("RFA_ZIGZAG_EXCHANGE", "RFA_BENCH_FORCE_RCCL", "TORCHELASTIC_RUN_ID"):
                 env.pop(k_, None)
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_ring_baseline.py"),
                                            str(s_rank), str(hk), str(threads), "fwd" if fwd_only else "fwdbwd"],
@@ -583,8 +583,6 @@ def main():
     # multi-step path — this script's N > 1 branches (RCCL barrier / all_reduce, fixed-count spin-up, comm block)
     # on a one-GPU box.  The line it prints is marked and is not a measurement.
     forced = world == 1 and os.environ.get("RFA_BENCH_FORCE_RCCL") == "1"
-    if forced:
-        os.environ["RFA_TEST_FORCE_STEPS"] = "1"
     multi = world > 1 or forced
     if multi:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -593,7 +591,10 @@ def main():
 
     import ring_flash_attn as R
     from ring_flash_attn import config as rfa_config
-    from ring_flash_attn import utils as rfa_utils
+    from ring_flash_attn import _testing as rfa_testing
+
+    if forced:
+        rfa_testing.force_steps(True)
     from ring_flash_attn.zigzag_ring_flash_attn import exchange_mode, _wire_fp32
 
     hk = args.kv_heads
@@ -749,7 +750,7 @@ def main():
     if multi:
         mode = exchange_mode(kv.detach()[:, :, 0], world, q.detach()) if wl == "zigzag" else {"llama3": "allgather+reduce_scatter"}.get(wl, "ring")
         comp = float("nan")
-        rfa_utils.set_loopback((rank, world))
+        rfa_testing.set_loopback((rank, world))
         try:
             for _ in range(2):
                 step()
@@ -758,7 +759,7 @@ def main():
         except Exception as e:
             errors["compute_only"] = f"{type(e).__name__}: {e}"
         finally:
-            rfa_utils.set_loopback(None)
+            rfa_testing.set_loopback(None)
         result["comm"] = {
             "exchange": mode,
             "dkv_wire": ("fp32" if (_wire_fp32() or mode == "ring") else "bf16") if wl == "zigzag" else None,
@@ -770,20 +771,20 @@ def main():
             "autotune": tune_rep,
             "probe": probe_rep,
             "note": "compute_only = this rank's exact kernel sequence with the exchange looped back to local buffers "
-                    "(ring_flash_attn.utils.set_loopback), max over ranks; exposed = ms_per_step - compute_only",
+                    "(ring_flash_attn._testing.set_loopback), max over ranks; exposed = ms_per_step - compute_only",
         }
 
     if world == 1 and args.virtual_world > 1:
         vw = args.virtual_world
         vr = args.virtual_rank if args.virtual_rank >= 0 else vw // 2 - 1 + (vw > 2)
-        rfa_utils.set_loopback((vr, vw))
+        rfa_testing.set_loopback((vr, vw))
         try:
             for _ in range(2):
                 step()
             counter[0] = 0
             vms = timed(args.steps) / args.steps * 1e3
         finally:
-            rfa_utils.set_loopback(None)
+            rfa_testing.set_loopback(None)
         result["virtual_ring"] = {
             "world": vw, "rank": vr, "ms_per_step": vms, "ideal_ms": vw * ms, "efficiency": vw * ms / vms,
             "exchange": exchange_mode(kv.detach()[:, :, 0], vw) if wl == "zigzag" else None,
@@ -797,7 +798,7 @@ def main():
         from ring_flash_attn import backend as rfa_backend
 
         timer = InStepTimer(rfa_backend.get_backend())
-        rfa_backend.set_backend(timer)
+        rfa_testing.set_backend(timer)
         rounds = max(2, min(args.steps // 4, 16))           # instrumented steps = rounds x kinds, one kind per step
         span_ms = None
         try:
@@ -824,7 +825,7 @@ def main():
             single = None
         finally:
             timer.kind, timer.prefix = None, 0
-            rfa_backend.set_backend(None)
+            rfa_testing.set_backend(None)
         spill = rfa_config.get().bwd_ds_spill
         instep = {}
         if single is None:

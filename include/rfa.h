@@ -116,7 +116,11 @@ typedef struct {
    * /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:131,135,266).  dropout_p = 0: off.  An attention
    * probability is kept with probability keep/256, keep = round((1 - dropout_p) * 256), and kept ones are scaled by
    * 256 / keep, keep = round((1 - dropout_p) * 256) — the reciprocal of the probability the mask really keeps with, so that
-   * E[dropout(P)] = P for every p —; lse is that of the undropped softmax (flash_attn semantics).  The keep mask is a pure
+   * E[dropout(P)] = P for every p —; lse is that of the undropped softmax (flash_attn semantics).  DEVIATION from
+   * flash_attn, deliberate: flash_attn also quantises its threshold to 8 bits but keeps scaling by 1 / (1 - dropout_p),
+   * which is biased by up to 0.4 % (p = 0.17: 256 / 212 = 1.2075 here, 1 / 0.83 = 1.2048 there); its Philox mask cannot
+   * be reproduced without the package anyway, so no bit-level parity is lost (tests/test_oracle.py pins the factor
+   * and the unbiasedness against values written out by hand, not against the oracle).  The keep mask is a pure
    * function of (dropout_seed, batch, head_offset + head, q_pos_offset + query position, k_pos_offset + key
    * position) — csrc/rfa_common.hpp: drop_word — where a position is the row inside the dense sequence, or the
    * absolute row of the packed tensor for cu_seqlens input; a rank that holds rows [a, b) of a longer stream passes
@@ -271,7 +275,7 @@ typedef struct {
 
 int rfa_abi_version(void);
 /* identity of this build: the first 16 hex digits of the sha256 over the library's sources, compiled into the binary by
- * the build recipe (ring-flash-attention_amd/build.py).  Measurement files (profiles/*_traffic.json) record the id of
+ * the build recipe (ring-flash-attention_amd/build.py).  Measurement files (profiles/r*_traffic.json) record the id of
  * the library they were collected on; bench.py only quotes them for a library with the same id. */
 const char *rfa_build_id(void);
 const char *rfa_strerror(int status);

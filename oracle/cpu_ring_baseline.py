@@ -52,8 +52,9 @@ def main():
         import ring_flash_attn as R
         from oracle.oracle_backend import OracleBackend
         from ring_flash_attn import backend
+        from ring_flash_attn import _testing
 
-        backend.set_backend(OracleBackend())
+        _testing.set_backend(OracleBackend())
         fn = R.zigzag_ring_flash_attn_func
     g = torch.Generator().manual_seed(42 + rank)
     q = torch.randn(1, s_rank, H, D, generator=g).to(torch.bfloat16)

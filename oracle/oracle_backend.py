@@ -3,7 +3,7 @@
 An object with the interface of `ring_flash_attn.backend.HipBackend`, implemented on CPU with
 the oracle (oracle/flash_attn_ref.py) and the reference's merge / accumulate formulas
 (/root/reference/ring_flash_attn/utils.py:40-48; zigzag_ring_flash_attn.py:164-187).  Tests inject
-it with `ring_flash_attn.backend.set_backend(OracleBackend())` to run the *schedules* of the
+it with `ring_flash_attn._testing.set_backend(OracleBackend())` to run the *schedules* of the
 package under gloo without a GPU.  It mimics the reference's rounding points (block results are
 rounded to the io dtype before they are merged / accumulated in fp32) so that the schedules can
 be compared tightly against golden fixtures produced by the unmodified reference code.

@@ -30,6 +30,7 @@ HIP_SOURCES = ["rfa_fwd.hip", "rfa_bwd.hip", "rfa_bigd.hip", "rfa_dqs.hip", "rfa
 FWD64_SOURCE = os.path.join("experiments", "rfa_fwd64.hip")
 API_SOURCE = "rfa_api.cpp"
 HEADERS = ["rfa_common.hpp", "rfa_kernels.hpp", os.path.join(ROOT, "include", "rfa.h")]
+EXPORTS_MAP = "rfa_exports.map"          # linker version script: only rfa_* is bindable
 
 
 def _hipcc():
@@ -70,19 +71,19 @@ def _run(cmd, cwd=None):
 def build_lib(force=False, with_fwd64=False):
     hip_sources = HIP_SOURCES + ([FWD64_SOURCE] if with_fwd64 else [])
     srcs = [os.path.join(CSRC, s) for s in hip_sources + [API_SOURCE]]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(CSRC, EXPORTS_MAP)]
     extra = "fwd64" if with_fwd64 else ""
     if not force and not _stale(LIB, deps, extra):
         return LIB
     # the build id (rfa_build_id()): digest of exactly the sources that go into the binary
     build_id = _digest(deps, extra)[:16]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-Wno-unused-result", "-Wno-inline-asm", f'-DRFA_BUILD_ID="{build_id}"']
+           "-fno-gpu-rdc", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wno-unused-result", "-Wno-inline-asm", f'-DRFA_BUILD_ID="{build_id}"']
     if with_fwd64:
         cmd += ["-DRFA_WITH_FWD64=1", "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in hip_sources]
     cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
-    cmd += ["-o", LIB]
+    cmd += ["-Wl,--version-script=" + os.path.join(CSRC, EXPORTS_MAP), "-o", LIB]
     _run(cmd)
     _stamp(LIB, deps, extra)
     return LIB

@@ -64,6 +64,9 @@ static bool fwd_use_4x64(const rfa_fwd_args* a) {
   return a->fwd_form == RFA_FWD_4x64;
 }
 
+// the library is built with -fvisibility=hidden: the C ABI below (include/rfa.h) is everything a loader can bind —
+// no rfa::launch_* internals, no kernel stubs (tests/test_abi.py::test_library_exports_only_the_c_abi)
+#pragma GCC visibility push(default)
 extern "C" {
 
 int rfa_abi_version(void) { return RFA_ABI_VERSION; }
@@ -640,3 +643,4 @@ int rfa_lse_unflatten(float* dst, const float* src, const int32_t* cu_seqlens, i
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

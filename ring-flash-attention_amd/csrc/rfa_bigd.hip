@@ -887,7 +887,7 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
 #pragma unroll
       for (int i = 0; i < kPieces; ++i) issue_piece(nxt, i);
     }
-    if (RFA_BG_X_SYNC && RFA_BG_X_DMA) wait_next_tile(spill && active);
+    if (bool(RFA_BG_X_SYNC) & bool(RFA_BG_X_DMA)) wait_next_tile(spill && active);
     if (++cg >= G) {
       cg = 0;
       j -= nsplit;

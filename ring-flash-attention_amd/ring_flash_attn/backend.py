@@ -5,9 +5,9 @@ librfa_hip.so (include/rfa.h) and launches on torch's current HIP stream.  It is
 for what the reference imports from the CUDA-only `flash_attn` package
 (/root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:3, ring_flash_attn_varlen.py:3-6).
 
-There is deliberately NO CPU implementation here.  `set_backend()` exists so that the test
-suite can inject the CPU oracle (oracle/flash_attn_ref.py) to exercise the *schedules* under
-gloo on a GPU-less machine; the product never selects anything but HipBackend, and HipBackend
+There is deliberately NO CPU implementation here.  The test suite injects the CPU oracle
+(oracle/flash_attn_ref.py) through ring_flash_attn._testing.set_backend to exercise the *schedules*
+under gloo on a GPU-less machine; the product never selects anything but HipBackend, and HipBackend
 raises if the extension is missing or a tensor is not on a HIP device.
 """
 import ctypes as C
@@ -59,6 +59,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _C.load()
         self._ds_pool = {}            # (device index, stream handle) -> the ONE reusable dS scratch of that stream
+        self._ds_capped = {}          # same key -> [backwards left until growth of a memory-capped scratch is retried]
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -270,11 +271,21 @@ class HipBackend:
             return None
         least = self.lib.rfa_bwd_ds_scratch_min_bytes(C.byref(a))
         want = min(full, max(_spill_limit(), 0))
+        capped = False
         key = (device.index if device.index is not None else torch.cuda.current_device(),
                torch.cuda.current_stream(device).cuda_stream) if device.type == "cuda" else ("cpu", 0)
         buf = self._ds_pool.get(key)
-        if buf is not None and buf.numel() >= min(want, full):
-            return buf                                      # (the steady state: no query, no allocation)
+        if buf is not None:
+            if buf.numel() >= min(want, full):
+                return buf                                  # (the steady state: no query, no allocation)
+            # a buffer that was CAPPED by the free-memory fraction when it was taken is smaller than `want` for ever:
+            # keep using it (the hand-off runs in chunks over it) instead of querying the allocator, dropping and
+            # re-making it in every backward; growth is retried once in a while
+            retry = self._ds_capped.get(key)
+            if retry is not None and buf.numel() >= least:
+                retry[0] -= 1
+                if retry[0] > 0:
+                    return buf
         if want < least:
             _log_once("spill-limit", f"ring_flash_attn: the dS hand-off needs at least {least / 2**30:.2f} GiB per chunk "
                                      f"(limit {want / 2**30:.2f} GiB): this backward runs the 7-GEMM form")
@@ -286,6 +297,7 @@ class HipBackend:
             cap = int(_spill_frac() * (free + cached + have))
             if cap < want:
                 want = cap
+                capped = True
         if want < least:
             _log_once("spill-mem", f"ring_flash_attn: not enough free memory for a dS hand-off chunk ({least / 2**30:.2f} GiB): "
                                    "this backward runs the 7-GEMM form")
@@ -299,11 +311,18 @@ class HipBackend:
                                    "this backward runs the 7-GEMM form")
             return None
         self._ds_pool[key] = buf
+        if capped:
+            self._ds_capped[key] = [_SPILL_GROW_RETRY]
+        else:
+            self._ds_capped.pop(key, None)
         return buf
 
     def release_scratch(self):
-        """drop the reusable dS scratch buffers (they are re-made on demand)"""
+        """drop the reusable dS scratch buffers (they are re-made on demand): up to config.ds_spill_max_bytes per device
+        and stream that the pool otherwise holds for the life of the process — call it before a phase that needs the
+        memory (evaluation with long sequences, checkpoint loading), or from an out-of-memory handler"""
         self._ds_pool.clear()
+        self._ds_capped.clear()
 
     # ------------------------------------------------------------------ side kernels
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):
@@ -413,11 +432,12 @@ def _plan_overrides():
     if c.dkdv_wide == 0:
         form = _C.DKDV_128
     elif c.dkdv_nsplit > 0 or c.dkdv_wide == 1:
-        form = _C.DKDV_256 if c.dkdv_nsplit > 0 else _C.DKDV_AUTO
+        form = _C.DKDV_256               # (forced: the C plan takes form == 256 as given; nsplit 0 = its own choice)
     return form, c.dkdv_nsplit
 
 
 _SPILL_CHECK_ABOVE = 256 << 20      # bytes: scratch requests up to this size are simply attempted
+_SPILL_GROW_RETRY = 64               # backwards between two attempts to grow a scratch that free memory had capped
 
 _LOGGED = set()
 
@@ -430,20 +450,12 @@ def _log_once(key, msg):
 
 
 _backend = None
-_injected = None
-
-
-def set_backend(backend):
-    """TEST HOOK ONLY: inject an object with HipBackend's interface (e.g. the CPU oracle from
-    oracle/).  Pass None to restore the HIP backend.  Nothing in the package calls this."""
-    global _injected
-    _injected = backend
 
 
 def get_backend():
+    """the operator backend of this process: the HIP library (raises if librfa_hip.so is missing — there is no CPU
+    path).  Tests and bench.py's in-step timer replace it through ring_flash_attn._testing.set_backend."""
     global _backend
-    if _injected is not None:
-        return _injected
     if _backend is None:
-        _backend = HipBackend()   # raises RuntimeError if librfa_hip.so is missing
+        _backend = HipBackend()
     return _backend

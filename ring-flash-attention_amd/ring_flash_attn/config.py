@@ -26,7 +26,6 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | dkdv_wide, dkdv_nsplit    | RFA_DKDV_WIDE, RFA_DKDV_NSPLIT  | unset   | dK/dV launch plan overrides (tuning / tests) |
 | fwd_kv_nsplit             | RFA_FWD_KV_NSPLIT               | 0       | split-KV forward launches: 0 chosen from the shapes, 1 off, 2..8 forced (tuning / tests) |
 | tuning_log                | RFA_TUNING_LOG                  | 0       | print autotune decisions on rank 0 |
-| force_steps               | RFA_TEST_FORCE_STEPS            | 0       | TEST HOOK: keep the multi-step path on a one-rank group (RCCL calls on a one-GPU box) |
 """
 import contextlib
 import dataclasses
@@ -90,7 +89,6 @@ class Config:
     dkdv_nsplit: int = 0         # 0 unset
     fwd_kv_nsplit: int = 0       # 0: chosen from the shapes; 1: never split; 2..8 forced
     tuning_log: bool = False
-    force_steps: bool = False
 
     @staticmethod
     def from_env(env=None) -> "Config":
@@ -138,8 +136,6 @@ class Config:
             c.fwd_kv_nsplit = _int("RFA_FWD_KV_NSPLIT", r)
         if (r := get("RFA_TUNING_LOG")) is not None:
             c.tuning_log = _bool("RFA_TUNING_LOG", r)
-        if (r := get("RFA_TEST_FORCE_STEPS")) is not None:
-            c.force_steps = _bool("RFA_TEST_FORCE_STEPS", r)
         return c
 
 

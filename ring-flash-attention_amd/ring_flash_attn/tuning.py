@@ -25,7 +25,7 @@ import time
 import torch
 import torch.distributed as dist
 
-from . import config
+from . import config, utils
 
 _LOCK = threading.Lock()
 _TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
@@ -86,18 +86,16 @@ def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
     through to a measurement or the shape rule, which all ranks take alike.  Records written by
     `autotune_zigzag_exchange` are agreed by construction (it is a collective).  Not under stream capture (the result
     could not be read back): there only an already agreed record is used."""
-    from . import utils
-
     key = _key(world, q_shape, k_shape, dtype, group)
     inst = (_group_instance(group), key)
     if inst in _AGREED:
         return _TUNED.get(key)
-    if utils._LOOPBACK is not None or world < 2:
+    if utils._loopback() is not None or world < 2:
         return _TUNED.get(key)
     if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
         return None
     code = _CODES[_TUNED.get(key)]
-    on_host = dist.get_backend(group) == "gloo" or device.type != "cuda"
+    on_host = utils.backend_of(group) == "gloo" or device.type != "cuda"
     t = torch.tensor([code, -code], dtype=torch.int32, device="cpu" if on_host else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     hi, lo = int(t[0].item()), -int(t[1].item())
@@ -122,11 +120,9 @@ def can_measure(group, q) -> bool:
     tensors on an RCCL group of several ranks (gloo groups are the CPU / shared-GPU test paths), no exchange loopback
     installed, outside stream capture, dynamo tracing and inference mode (the scratch tensors of the measurement would
     be inference tensors, which autograd refuses to save: ADVICE r4)"""
-    from . import utils
-
-    if utils._LOOPBACK is not None or not q.is_cuda:
+    if utils._loopback() is not None or not q.is_cuda:
         return False
-    if dist.get_backend(group) == "gloo" or dist.get_world_size(group) < 2:
+    if utils.backend_of(group) == "gloo" or dist.get_world_size(group) < 2:
         return False
     if torch.compiler.is_compiling() or torch.cuda.is_current_stream_capturing() or torch.is_inference_mode_enabled():
         return False
@@ -163,7 +159,7 @@ def _sync(dev):
 
 
 def _max_over_ranks(value, group, dev):
-    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend(group) != "gloo" else "cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=dev if utils.backend_of(group) != "gloo" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t.item()
 
@@ -238,7 +234,7 @@ def comm_probe(group, device, nbytes, iters=5, warm=2):
     all-to-all of `nbytes` per peer slot, and one neighbour hop of `nbytes` — the three transfers of the schedules.
     Collective over `group`."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    gloo = dist.get_backend(group) == "gloo"
+    gloo = utils.backend_of(group) == "gloo"
     dev = torch.device("cpu") if gloo else device
     n = max(1, nbytes // 2)
     src = torch.zeros(n, dtype=torch.bfloat16, device=dev)

@@ -62,10 +62,38 @@ def unflatten_varlen_lse(lse: torch.Tensor, cu_seqlens: torch.Tensor, max_seqlen
     return get_backend().lse_unflatten(lse, cu_seqlens, max_seqlen)
 
 
+# Test / measurement hooks (exchange loopback, forced multi-step path, host staging for gloo groups that share one GPU):
+# their state and setters live in ring_flash_attn._testing, which nothing in the package imports; production carries
+# this one `None`.
+_TEST = None
+
+
+def _loopback():
+    return _TEST.loopback if _TEST is not None else None
+
+
+_BACKEND_OF = {}
+
+
+def backend_of(process_group) -> str:
+    """the group's torch.distributed backend name, resolved ONCE per group (not a `dist.get_backend()` per transfer)"""
+    g = dist.group.WORLD if process_group is None else process_group
+    key = (getattr(g, "group_name", None), id(g))
+    b = _BACKEND_OF.get(key)
+    if b is None:
+        b = _BACKEND_OF[key] = str(dist.get_backend(process_group))
+    return b
+
+
 def _needs_host_staging(process_group, t: torch.Tensor) -> bool:
-    # gloo cannot move device memory.  Only reached by the single-GPU multi-process parity test
-    # (several ranks sharing one MI355X); production groups are nccl(=RCCL).
-    return t.is_cuda and dist.get_backend(process_group) == "gloo"
+    """gloo cannot move device memory.  The product transport is RCCL; several TEST ranks sharing one MI355X stage
+    through the host after ring_flash_attn._testing.allow_host_staging() — anything else fails loudly here."""
+    if not (t.is_cuda and backend_of(process_group) == "gloo"):
+        return False
+    if _TEST is None or not _TEST.host_staging:
+        raise RuntimeError("ring_flash_attn: device tensors on a gloo process group — the exchange runs on RCCL "
+                           "(init_process_group('nccl')); gloo cannot move device memory")
+    return True
 
 
 # ---------------------------------------------------------------------------------------------
@@ -91,35 +119,20 @@ def comm_stream(device: torch.device) -> "torch.cuda.Stream":
 
 
 def _use_side_stream(process_group, t: torch.Tensor) -> bool:
-    return t.is_cuda and dist.get_backend(process_group) != "gloo"
-
-
-# ---------------------------------------------------------------------------------------------
-# MEASUREMENT HOOK (bench.py `comm.exposed_ms`, tools/virtual_ring_bench.py): with a loopback
-# (rank, world) installed, RingComm / AllGatherComm / the dK/dV exchanges move data between LOCAL
-# buffers only, so ONE process executes the exact kernel sequence of rank `rank` of a `world`-rank
-# job with no communication — "measured step minus loopback step" is the exposed exchange time.
-# The results are meaningless (every peer's K/V is a copy of the local one); nothing in the package
-# installs it.
-_LOOPBACK = None
-
-
-def set_loopback(rank_world=None):
-    global _LOOPBACK
-    _LOOPBACK = rank_world
+    return t.is_cuda and backend_of(process_group) != "gloo"
 
 
 def single_rank(world_size: int) -> bool:
-    """True when a schedule may collapse to its single-kernel form.  config.force_steps (RFA_TEST_FORCE_STEPS=1, tests only:
-    tests/test_gpu_rccl_world1.py) keeps the multi-step code path — exchange buffers, collectives, side stream,
-    fp32 accumulators — even on a one-rank group, which is how the RCCL calls get exercised on a one-GPU box."""
-    return world_size == 1 and not config.get().force_steps
+    """True when a schedule may collapse to its single-kernel form (a one-rank group; _testing.force_steps keeps the
+    multi-step path even there: the RCCL calls on a one-GPU box)"""
+    return world_size == 1 and not (_TEST is not None and _TEST.force_steps)
 
 
 def group_rank_world(process_group):
     """(rank, world_size) of the group — the one place the schedules ask for it"""
-    if _LOOPBACK is not None:
-        return _LOOPBACK
+    lb = _loopback()
+    if lb is not None:
+        return lb
     return dist.get_rank(process_group), dist.get_world_size(process_group)
 
 
@@ -145,7 +158,7 @@ class RingComm:
         self.send_rank = (self.rank + 1) % self.world_size
         self.recv_rank = (self.rank - 1) % self.world_size
 
-        if process_group is not None and _LOOPBACK is None:
+        if process_group is not None and _loopback() is None:
             self.send_rank = dist.get_global_rank(self._process_group, self.send_rank)
             self.recv_rank = dist.get_global_rank(self._process_group, self.recv_rank)
 
@@ -173,7 +186,7 @@ class RingComm:
             res = self._recv_buffer(to_send)
         else:
             res = recv_tensor
-        if _LOOPBACK is not None:
+        if _loopback() is not None:
             self._local.append((to_send, res))
             return res
         if _needs_host_staging(self._process_group, to_send):
@@ -194,7 +207,7 @@ class RingComm:
     def commit(self):
         if self._reqs is not None:
             raise RuntimeError("commit called twice")
-        if _LOOPBACK is not None:
+        if _loopback() is not None:
             for src, dst in self._local:
                 dst.copy_(src)
             self._reqs = []
@@ -278,8 +291,8 @@ class AllGatherComm:
         self.handles = []
 
     def all_gather(self, output_tensor: torch.Tensor, input_tensor: torch.Tensor):
-        if _LOOPBACK is not None:
-            world = _LOOPBACK[1]
+        if _loopback() is not None:
+            world = _loopback()[1]
             output_tensor.view(world, -1).copy_(input_tensor.reshape(1, -1).expand(world, -1))
             return
         if _needs_host_staging(self.group, input_tensor):
@@ -308,11 +321,12 @@ def reduce_scatter_async(output: torch.Tensor, input_: torch.Tensor, group=None)
     """output = this rank's dim-0 chunk of the sum over ranks of input_; the returned handle's wait() makes the
     compute stream wait for it.  gloo (tests: device memory shared by several ranks, or 16-bit CPU tensors,
     which gloo would add in their own precision): fp32 all_reduce on the host."""
-    if _LOOPBACK is not None:
-        rank, world = _LOOPBACK
+    if _loopback() is not None:
+        rank, world = _loopback()
         output.copy_(input_.chunk(world, dim=0)[rank].reshape(output.shape))
         return _Work(None)
-    if dist.get_backend(group) == "gloo" and (input_.is_cuda or input_.dtype not in (torch.float32, torch.float64)):
+    if backend_of(group) == "gloo" and (input_.dtype not in (torch.float32, torch.float64)
+                                        or _needs_host_staging(group, input_)):
         return _sum_on_host(output, input_, group)
     return _post(group, input_, lambda: dist.reduce_scatter_tensor(output, input_, group=group, async_op=True))
 
@@ -330,10 +344,10 @@ class Agreement:
 
     def __init__(self, process_group, flag: bool, device: torch.device):
         self._value, self._event, self._host, self._dev = None, None, None, None
-        if _LOOPBACK is not None:
+        if _loopback() is not None:
             self._value = bool(flag)
             return
-        if device.type == "cuda" and dist.get_backend(process_group) != "gloo":
+        if device.type == "cuda" and backend_of(process_group) != "gloo":
             side = comm_stream(device)
             with torch.cuda.stream(side):
                 self._dev = torch.full((1,), int(bool(flag)), dtype=torch.int32, device=device)
@@ -361,7 +375,7 @@ def reduce_scatter(output: torch.Tensor, input_: torch.Tensor, group=None):
 
 def all_to_all_async(output: torch.Tensor, input_: torch.Tensor, group=None) -> _Work:
     """dim-0 chunk j of input_ goes to rank j; dim-0 chunk i of output comes from rank i"""
-    if _LOOPBACK is not None:
+    if _loopback() is not None:
         output.copy_(input_)
         return _Work(None)
     if _needs_host_staging(group, input_):

@@ -54,17 +54,19 @@ def run_rank(rank, W, port, cfg_kw, cu, use_hip, heads_k_stride, ret):
         torch.set_num_threads(2)
         dist.init_process_group("gloo", rank=rank, world_size=W)
         from ring_flash_attn import backend, substitute_hf_flash_attn, update_ring_flash_attn_params
+        from ring_flash_attn import _testing
         from ring_flash_attn.adapters.hf_adapter import ATTN_IMPLEMENTATION
 
         if use_hip:
             dev, dtype = torch.device("cuda:0"), torch.bfloat16
             torch.cuda.set_device(dev)
-            backend.set_backend(None)
+            _testing.set_backend(None)
+            _testing.allow_host_staging(True)       # several gloo ranks share this one GPU
         else:
             from oracle.oracle_backend import OracleBackend
 
             dev, dtype = torch.device("cpu"), torch.float32
-            backend.set_backend(OracleBackend())
+            _testing.set_backend(OracleBackend())
         substitute_hf_flash_attn(None, heads_k_stride)
         model = build_model(cfg_kw, ATTN_IMPLEMENTATION, dtype, dev)
         ids, pos, w = make_batch(cu, cfg_kw["vocab_size"])

@@ -47,8 +47,11 @@ def run_rank(rank, W, port, c, outdir):
         dist.init_process_group("gloo", rank=rank, world_size=W)
         import ring_flash_attn as R
         from ring_flash_attn import backend
+        from ring_flash_attn import _testing
 
-        backend.set_backend(None)
+        _testing.set_backend(None)
+
+        _testing.allow_host_staging(True)       # several gloo ranks share this one GPU
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         q, k, v, do = [t.to(dev) for t in shard(c, rank, global_inputs(c))]

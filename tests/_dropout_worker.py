@@ -30,15 +30,17 @@ def run(rank, W, port, ret, use_hip, stride):
         dist.init_process_group("gloo", rank=rank, world_size=W)
         import ring_flash_attn as R
         from ring_flash_attn import backend
+        from ring_flash_attn import _testing
 
         if use_hip:
             dev = torch.device("cuda:0")
-            backend.set_backend(None)
+            _testing.set_backend(None)
+            _testing.allow_host_staging(True)       # several gloo ranks share this one GPU
         else:
             from oracle.oracle_backend import OracleBackend
 
             dev = torch.device("cpu")
-            backend.set_backend(OracleBackend())
+            _testing.set_backend(OracleBackend())
         q, k, v, do = inputs()
         T = CU[-1] // W
         sl = slice(rank * T, (rank + 1) * T)

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_rccl_world1.py: ONE process, ONE GPU, process group backend "nccl" (= RCCL) with
-world_size 1, RFA_TEST_FORCE_STEPS=1 — every schedule then runs its multi-step code path (exchange buffers,
+world_size 1, ring_flash_attn._testing.force_steps() — every schedule then runs its multi-step code path (exchange buffers,
 RCCL all_gather / all_to_all / reduce_scatter / batched isend+irecv to itself, the side stream, fp32
 accumulators, final casts) instead of collapsing to one kernel.  At world size 1 the result must equal plain
 attention over the local sequence, which the CPU oracle provides.  This is the only place a one-GPU box can
@@ -7,7 +7,6 @@ execute the RCCL calls of the product path (gloo, used by the multi-rank parity 
 import os
 import sys
 
-os.environ["RFA_TEST_FORCE_STEPS"] = "1"
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,6 +30,9 @@ def check(name, got, ref, atol, rtol=0.0):
 def main(port):
     from oracle import flash_attn_ref as O
     import ring_flash_attn as R
+    from ring_flash_attn import _testing
+
+    _testing.force_steps(True)
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)

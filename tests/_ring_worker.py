@@ -50,6 +50,7 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
         import make_golden as MG
         import ring_flash_attn as R
         from ring_flash_attn import backend
+        from ring_flash_attn import _testing
 
         if via_reference:
             # INTEGRATION.md route B: the UNMODIFIED reference schedules on top of the shipped `flash_attn`
@@ -69,13 +70,14 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
         if use_hip:
             dev = torch.device("cuda:0")
             torch.cuda.set_device(dev)
-            backend.set_backend(None)
+            _testing.set_backend(None)
+            _testing.allow_host_staging(True)       # several gloo ranks share this one GPU
             tol = TOL_HIP
         else:
             from oracle.oracle_backend import OracleBackend
 
             dev = torch.device("cpu")
-            backend.set_backend(OracleBackend())
+            _testing.set_backend(OracleBackend())
             tol = TOL_ORACLE
         errs = []
         compiled = os.environ.get("RFA_TEST_COMPILE") == "1"

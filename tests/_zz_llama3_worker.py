@@ -38,16 +38,18 @@ def run_rank(rank, W, port, c, use_hip, ret):
         dist.init_process_group("gloo", rank=rank, world_size=W)
         import ring_flash_attn as R
         from ring_flash_attn import backend
+        from ring_flash_attn import _testing
 
         if use_hip:
             dev = torch.device("cuda:0")
             torch.cuda.set_device(dev)
-            backend.set_backend(None)
+            _testing.set_backend(None)
+            _testing.allow_host_staging(True)       # several gloo ranks share this one GPU
         else:
             from oracle.oracle_backend import OracleBackend
 
             dev = torch.device("cpu")
-            backend.set_backend(OracleBackend())
+            _testing.set_backend(OracleBackend())
         q, k, v, do = [shard(t, rank, W).to(dev) for t in make_inputs(c)]
         cu = torch.tensor(c["cu"], dtype=torch.int32)
         kw = dict(causal=c["causal"], window_size=tuple(c.get("window", (-1, -1))), return_attn_probs=True)

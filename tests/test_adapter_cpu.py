@@ -44,11 +44,12 @@ def test_sliding_window_is_honoured(single_rank_group):
     window_size=(w, w) when the key length exceeds it) and the kernels implement it (flash_attn semantics);
     a window that covers the whole key range is a no-op."""
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from ring_flash_attn.adapters import hf_adapter as A
     from oracle import flash_attn_ref as O
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     try:
         A.substitute_hf_flash_attn(None, 1)
         A.update_ring_flash_attn_params(torch.tensor([0, 24], dtype=torch.int32), None)
@@ -62,7 +63,7 @@ def test_sliding_window_is_honoured(single_rank_group):
         assert (win.double() - ref_win).abs().max() < 2e-2
         assert (ref_win - ref_full).abs().max() > 0.1
     finally:
-        backend.set_backend(None)
+        _testing.set_backend(None)
         A.DATA_PARAMS.clear()
 
 

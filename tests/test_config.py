@@ -9,7 +9,7 @@ def test_defaults_and_environment(monkeypatch):
 
     c = config.Config.from_env({})
     assert (c.zigzag_exchange, c.zigzag_varlen_exchange, c.dkv_wire_fp32, c.autotune, c.bwd_ds_spill) == ("auto", "ring", False, False, True)
-    assert c.kv_keep and c.kv_keep_bytes == c.kv_keep_total_bytes == 4 << 30 and not c.force_steps
+    assert c.kv_keep and c.kv_keep_bytes == c.kv_keep_total_bytes == 4 << 30 and not hasattr(c, "force_steps")
     c = config.Config.from_env({"RFA_ZIGZAG_EXCHANGE": "Ring", "RFA_DKV_WIRE": "fp32", "RFA_ZIGZAG_KV_CACHE": "0",
                                 "RFA_DKDV_NSPLIT": "3", "RFA_FWD_FORM": "4x64", "RFA_DS_SPILL_MAX_FRAC": "0.25",
                                 "RFA_FWD_KV_NSPLIT": "1"})

@@ -44,7 +44,8 @@ def _oracle(q, k, v, do, causal, window=(-1, -1), cu=None, drop=None):
     (192, 1, 2500, 2500, 2, 1, True, BF),          # ... in the three-quarter instances (head dims <= 192 skip the padding quarter)
 ])
 def test_dense_forward_backward(D, B, Sq, Sk, H, Hk, causal, dtype):
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -91,7 +92,8 @@ def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk
     """the 5-GEMM backward at D = 136 .. 256 (the dK launch of rfa_bigd.hip stores dS, rfa_dqs.hip computes dQ from it in
     two 128-column launches, the second over the D - 128 columns that exist) against the oracle, against the 7-GEMM form
     (dK / dV bit-identical: the same kernel with and without the stores)"""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -124,7 +126,8 @@ def test_ds_spill_backward_at_head_dim_256(monkeypatch, Sq, Sk, causal, B, H, Hk
 def test_forward_merge_of_two_key_halves_equals_one_call():
     """the fused online merge epilogue at D = 256: keys split in two calls (the second one merging into the first's
     accumulators) against one call over all keys"""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -148,7 +151,8 @@ def test_forward_merge_of_two_key_halves_equals_one_call():
     (900, 333, 256, False, (-1, 50)),
 ])
 def test_sliding_windows(Sq, Sk, D, causal, window):
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -172,7 +176,8 @@ def test_sliding_windows(Sq, Sk, D, causal, window):
 
 @pytest.mark.parametrize("D,causal", [(256, True), (192, False)])
 def test_dropout(D, causal):
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -240,7 +245,8 @@ def test_schedules_over_several_ranks(monkeypatch, cfg):
 
 def test_head_dim_limits_of_the_c_abi():
     """D = 256 is accepted, 264 and 100 (not a multiple of 8) are RFA_ERR_HEAD_DIM — through the ctypes wrapper"""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()

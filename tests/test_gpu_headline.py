@@ -146,7 +146,8 @@ def test_headline_full_tensor_one_kv_group(single_rank_group, hk):
 
 
 def test_headline_constant_v_and_split_merge(single_rank_group):
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()

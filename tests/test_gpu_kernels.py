@@ -223,7 +223,8 @@ def test_merge_kernel_is_reference_update_out_and_lse():
 def test_sum_slots_kernel_strided_destination(dtype):
     """rfa_sum_slots: W io-dtype contributions summed in fp32 into a slice of a packed gradient (dense) and into a
     packed-sequence tensor (T,H,D); bit-exact against the same fp32 sum rounded once."""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -309,7 +310,8 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
     against the recompute backward on the same inputs (they share dK/dV bit for bit: same kernel, the spill
     only adds stores)."""
     from oracle import flash_attn_ref as O
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -365,7 +367,8 @@ def test_ds_handoff_in_head_group_chunks(B, Sq, Sk, H, Hk, causal, cu):
     import ctypes as C
 
     from ring_flash_attn import _C, config
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -439,7 +442,8 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
     against the 128-key form on the same inputs."""
     from oracle import flash_attn_ref as O
     from ring_flash_attn import _C
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -505,7 +509,8 @@ def test_ds_spill_packed_sequences_with_longer_keys(monkeypatch, causal):
     """dS-spill backward on packed sequences whose K/V are longer than Q (the llama3 shape: local queries against
     gathered keys, bottom-right aligned), with empty and 1-token sequences, against the oracle and against the
     recompute backward (dK/dV bit for bit)."""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -543,8 +548,9 @@ def test_torch_compile_fullgraph_on_gpu(single_rank_group):
     (no graph break) and reproduce the eager path bit for bit (test/test.sh:23-25 of the reference)."""
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
 
-    backend.set_backend(None)
+    _testing.set_backend(None)
     dev = _dev()
     g = torch.Generator().manual_seed(5)
     qkv = torch.randn(1, 640, 3, 4, 128, generator=g).to(BF).to(dev)
@@ -572,7 +578,8 @@ def test_sliding_window_kernels_match_oracle(Sq, Sk, D, causal, window):
     """window_left / window_right of rfa_fwd / rfa_bwd (flash_attn semantics; forwarded by the reference's llama3
     path and HF adapter) against the CPU oracle: forward, backward (plain and fp32-accumulate outputs)."""
     from oracle import flash_attn_ref as O
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be = get_backend()
@@ -634,7 +641,8 @@ def test_sliding_window_varlen_and_llama3_single_rank(single_rank_group):
 ])
 def test_dropout_dense_matches_oracle(D, H, Hk, Sq, Sk, causal, dtype):
     from oracle import flash_attn_ref as O
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -746,7 +754,8 @@ def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
 def test_head_dims_65_to_96_match_oracle(B, Sq, Sk, H, Hk, D, causal, dtype):
     """forward (plain and merged into fp32 accumulators) and backward (plain and += outputs) of the three-block instances
     against the CPU oracle; packed (cu_seqlens) input through the same instances"""
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -817,7 +826,8 @@ def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq
     """both forward forms on grids below the threshold: against the oracle, and against each other BIT FOR BIT (a wave's
     32 rows do not depend on how many waves share its workgroup) — plain outputs and the fused merge epilogue"""
     from oracle import flash_attn_ref as O
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -861,7 +871,8 @@ def test_fwd_split_kv_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, D, causal, n
 
     from oracle import flash_attn_ref as O
     from ring_flash_attn import _C
-    from ring_flash_attn.backend import get_backend, set_backend
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
 
     set_backend(None)
     be, dev = get_backend(), _dev()
@@ -928,12 +939,15 @@ def test_fwd_split_kv_packed_sequences(single_rank_group, monkeypatch):
 
 def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
     """packed sequences, half-sequence selectors and the fused fp32 merge epilogue: the zigzag varlen schedule forced
-    onto its multi-step path (RFA_TEST_FORCE_STEPS) with the library's choice of the forward form (128 rows on this
+    onto its multi-step path (_testing.force_steps) with the library's choice of the forward form (128 rows on this
     grid) against the 256-row form: identical bits"""
     import ring_flash_attn as R
 
     dev = _dev()
-    monkeypatch.setenv("RFA_TEST_FORCE_STEPS", "1")
+    from ring_flash_attn import _testing
+
+    _testing.force_steps(True)
+    _testing.allow_host_staging(True)          # (the one-rank gloo group of the test process, device tensors)
     monkeypatch.setenv("RFA_FWD_KV_NSPLIT", "1")
     g = torch.Generator().manual_seed(64)
     cu = torch.tensor([0, 128, 1248, 2240], dtype=torch.int32, device=dev)
@@ -945,4 +959,5 @@ def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
         monkeypatch.setenv("RFA_FWD_FORM", form)
         out, lse, _ = R.zigzag_ring_flash_attn_varlen_func(q, k, v, cu, 1120, causal=True, return_attn_probs=True)
         res[form] = (out.float().cpu(), lse.cpu())
+    _testing.reset()
     assert torch.equal(res["auto"][0], res["8x32"][0]) and torch.equal(res["auto"][1], res["8x32"][1])

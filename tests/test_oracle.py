@@ -207,6 +207,28 @@ def test_oracle_dropout_vs_fp64_autograd(B, Sq, Sk, H, Hk, D, causal):
         assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_dropout_rescale_is_the_reciprocal_of_the_quantised_keep_rate():
+    """the library (and this oracle, changed in lockstep) rescale kept probabilities by 256 / keep,
+    keep = round((1 - p) 256), NOT by flash_attn's 1 / (1 - p).  Pinned here against numbers written out by hand — not
+    against the oracle's own helper — and against the property the choice exists for: E[dropout(P)] = P."""
+    by_hand = {0.17: 212, 0.1: 230, 0.5: 128, 0.25: 192, 0.9: 26, 0.05: 243}          # round((1 - p) * 256)
+    for p, keep in by_hand.items():
+        assert R.drop_threshold(p) == keep
+    q, k, v = _rand((1, 64, 2, 32), 11), _rand((1, 64, 2, 32), 12), _rand((1, 64, 2, 32), 13)
+    v = torch.ones_like(v)                      # out = row sum of the dropped, rescaled probabilities: E = 1
+    p = 0.17
+    outs = []
+    for seed in range(48):
+        out = R._flash_attn_forward(q.float(), k.float(), v.float(), p, 32 ** -0.5, False,
+                                    rng_state=torch.tensor([1000 + seed, 0]))[0]
+        outs.append(out.double().mean().item())
+    mean = sum(outs) / len(outs)
+    # 48 x 8192 masked rows of 64 keys: the standard error of the mean is ~4e-4; flash_attn's factor 1 / (1 - p) on this
+    # mask (kept at 212 / 256) would give 212 / 256 / 0.83 = 0.99774, i.e. 2.3e-3 low
+    assert abs(mean - 1.0) < 1.2e-3, mean
+    assert abs(212 / 256 / 0.83 - 1.0) > 2e-3
+
+
 def test_dropout_mask_definition():
     """known-answer pins of the mask function (so that the C++ and the Python statement cannot drift together
     unnoticed), its position semantics, and its statistics"""

@@ -64,6 +64,7 @@ def test_kept_kv_is_owned_by_the_autograd_graph():
     import torch.multiprocessing as mp
     import _kv_cache_worker as KW
     from ring_flash_attn import zigzag_ring_flash_attn as Z, utils as U
+    from ring_flash_attn import _testing
 
     assert not hasattr(Z, "_KV_CACHE") and not hasattr(U, "_BACKWARD_EXPECTED") and not hasattr(U, "_GRAD_MODE_AT_CALL")
     mgr = mp.Manager()
@@ -233,9 +234,10 @@ def test_dropout_argument_checks(single_rank_group):
     import torch
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     try:
         g = torch.Generator().manual_seed(1)
         q = torch.randn(1, 64, 2, 32, generator=g).bfloat16().requires_grad_(True)
@@ -260,7 +262,7 @@ def test_dropout_argument_checks(single_rank_group):
             a = fn(qv, qv, qv, cu, 40, dropout_p=0.3, causal=True)
             assert not torch.equal(a, fn(qv, qv, qv, cu, 40, causal=True))
     finally:
-        backend.set_backend(None)
+        _testing.set_backend(None)
 
 
 def test_exchange_mode_auto_threshold(monkeypatch):
@@ -341,9 +343,10 @@ def test_torch_compile_captures_custom_ops(single_rank_group):
     import torch
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     try:
         g = torch.Generator().manual_seed(3)
         qkv = torch.randn(1, 32, 3, 2, 16, generator=g).to(torch.bfloat16)
@@ -387,7 +390,7 @@ def test_torch_compile_captures_custom_ops(single_rank_group):
         assert (qc.grad.float() - qe.grad.float()).abs().max() <= 1e-2 * qe.grad.float().abs().max()
         assert (kvc.grad.float() - kve.grad.float()).abs().max() <= 1e-2 * kve.grad.float().abs().max()
     finally:
-        backend.set_backend(None)
+        _testing.set_backend(None)
         torch._dynamo.reset()
 
 
@@ -402,10 +405,11 @@ def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
     import torch
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from oracle import flash_attn_ref as O
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     try:
         g = torch.Generator().manual_seed(0)
         B, S, H, D = 1, 512, 4, 64
@@ -426,7 +430,7 @@ def test_config1_ring_qkvpacked_w1_fp32_plumbing(single_rank_group):
         assert (lse.double() - rl).abs().max() < 2e-5
         assert (qkv.grad.double() - ref.grad).abs().max() < 5e-5 * max(1.0, ref.grad.abs().max().item())
     finally:
-        backend.set_backend(None)
+        _testing.set_backend(None)
 
 
 @pytest.mark.parametrize("W", [2, 3, 4, 6])
@@ -450,9 +454,10 @@ def _llama3_groups_rank(rank, W, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=W)
     import ring_flash_attn as R
     from ring_flash_attn import backend, config
+    from ring_flash_attn import _testing
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     g = torch.Generator().manual_seed(77)
     T, H, Hk, D = 96, 8, 4, 16
     cu = torch.tensor([0, 20, 61, 96], dtype=torch.int32)
@@ -495,10 +500,11 @@ def _llama3_window_rank(rank, W, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=W)
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from oracle import flash_attn_ref as O
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     g = torch.Generator().manual_seed(78)
     T, H, Hk, D = 96, 4, 2, 16
     cu = torch.tensor([0, 20, 61, 96], dtype=torch.int32)
@@ -547,10 +553,11 @@ def test_single_rank_window_through_public_api(single_rank_group):
     import torch
     import ring_flash_attn as R
     from ring_flash_attn import backend
+    from ring_flash_attn import _testing
     from oracle import flash_attn_ref as O
     from oracle.oracle_backend import OracleBackend
 
-    backend.set_backend(OracleBackend())
+    _testing.set_backend(OracleBackend())
     try:
         g = torch.Generator().manual_seed(4)
         qkv = torch.randn(1, 48, 3, 2, 16, generator=g).to(torch.bfloat16).requires_grad_(True)
@@ -559,7 +566,7 @@ def test_single_rank_window_through_public_api(single_rank_group):
         ref, _ = O.full_attention_fp64(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], True, window=(5, 0))
         assert (out.double() - ref).abs().max() < 2e-2 and qkv.grad is not None
     finally:
-        backend.set_backend(None)
+        _testing.set_backend(None)
 
 
 @pytest.mark.parametrize("W,case", [

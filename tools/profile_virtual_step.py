@@ -9,6 +9,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 dist.init_process_group("gloo", rank=0, world_size=1)
 import ring_flash_attn as R
 from ring_flash_attn import utils as U
+from ring_flash_attn import _testing
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 r = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -16,7 +17,7 @@ dev = torch.device("cuda:0")
 q = torch.randn(1, 8192, 32, 128, device=dev, dtype=torch.bfloat16, requires_grad=True)
 kv = torch.randn(1, 8192, 2, 8, 128, device=dev, dtype=torch.bfloat16, requires_grad=True)
 do = torch.randn_like(q)
-U.set_loopback((r, W))
+_testing.set_loopback((r, W))
 def step():
     q.grad = None; kv.grad = None
     out = R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)

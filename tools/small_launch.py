@@ -31,6 +31,7 @@ def main():
     dist.init_process_group("gloo", rank=0, world_size=1)
     import ring_flash_attn as R
     from ring_flash_attn import utils
+    from ring_flash_attn import _testing
 
     dev = torch.device("cuda:0")
     T, W, r, H, Hk, D = args.tokens, args.world, args.rank, args.heads, args.kv_heads, 128
@@ -41,7 +42,7 @@ def main():
     cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, True, r, W)
     cq, ck = cq.to(dev), ck.to(dev)
     fwd_flops = 4.0 * H * D * (T * r * T + T * T / 2.0)
-    utils.set_loopback((r, W))
+    _testing.set_loopback((r, W))
     print(f"llama3, rank {r} of {W} (loopback), {T} tokens per rank (one sequence of {T * W}), {H}/{Hk} heads, head dim {D}")
     print("| heads_k_stride | pass | ms | TFLOP/s | of 2.5 PF |")
     print("|---|---|---|---|---|")
@@ -68,7 +69,7 @@ def main():
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / n * 1e3
             print(f"| {stride} | {name} | {ms:.3f} | {fl / ms / 1e9:.0f} | {fl / ms / 1e9 / 2500:.3f} |", flush=True)
-    utils.set_loopback(None)
+    _testing.set_loopback(None)
 
 
 if __name__ == "__main__":
