@@ -704,7 +704,13 @@ def main():
     for _ in range(args.warmup):
         step()
     counter[0] = 0
+    torch.cuda.reset_peak_memory_stats(dev)
     elapsed = timed(args.steps)
+    # peak device memory of the timed steps (the reference names memory as its known limitation, README.md:154; the
+    # gather exchange form trades O(S_total) scratch for fewer transfers): allocator peak incl. the inputs, max over ranks
+    peak = torch.tensor([float(torch.cuda.max_memory_allocated(dev))], dtype=torch.float64, device=dev if multi else "cpu")
+    dist.all_reduce(peak, op=dist.ReduceOp.MAX)
+    peak_gib = peak.item() / 2 ** 30
 
     ms = elapsed / args.steps * 1e3
     its = args.steps / elapsed
@@ -737,6 +743,7 @@ def main():
             "world_size": world,
             "forward_only": fwd_only,
         },
+        "peak_device_memory_gib": round(peak_gib, 3),
         "algorithmic_tflops_per_gpu": per_gpu_flops * its / 1e12,
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
     }

@@ -47,7 +47,7 @@ def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world
 
 def llama3_flash_attn_prepare_cu_seqlens(cu_seqlens: torch.Tensor, causal: bool, rank: int, world_size: int):
     """Per-rank view of a packed token stream cut into `world_size` equal slices (integer work only; same results as
-    /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:10-60, checked bit for bit against 96 vectors the
+    /root/reference/ring_flash_attn/llama3_flash_attn_varlen.py:10-60, checked bit for bit against 72 vectors the
     reference produced: tests/test_abi.py::test_prepare_cu_seqlens_golden).
 
     cu_seqlens are the GLOBAL cumulative sequence lengths.  Returns

@@ -83,11 +83,11 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
         compiled = os.environ.get("RFA_TEST_COMPILE") == "1"
         if compiled:
             # the reference runs its tests a second time with the function under torch.compile at the full world
-            # size (test/test.sh:23-25, test/test_zigzag_ring_flash_attn_func.py:105-108).  With several ranks the
-            # schedules are opaque to dynamo (torch.compiler.disable: kernels interleaved with torch.distributed
-            # traffic): a compiled CALLER is traced up to the call, the schedule runs eagerly, tracing resumes
-            # behind it.  Every public function is replaced by such a compiled caller (with traced tensor work on
-            # both sides of the call) and must give the same results as the plain call, bit for bit.
+            # size (test/test.sh:23-25, test/test_zigzag_ring_flash_attn_func.py:105-108).  Every public function is
+            # replaced by a compiled caller (traced tensor work on both sides of the call); the schedule itself is
+            # captured as ONE registered operator per direction (ring_flash_attn/_ops.py) — no graph break — and must
+            # give the same results as the plain call, bit for bit.  RFA_TEST_COMPILE_BACKEND: inductor — torch.compile's
+            # default, what the reference's tests use — or aot_eager (dynamo + AOT autograd without code generation).
             import types
             from torch import _dynamo as dynamo
 
@@ -104,7 +104,7 @@ def run_rank(rank, W, port, names, use_hip, ret, via_reference=False):
                     a = tuple((t * 1 if torch.is_tensor(t) and t.is_floating_point() else t) for t in a)
                     res = fn(*a, **kw_)
                     return tuple((t + 0 if torch.is_tensor(t) else t) for t in res) if isinstance(res, tuple) else res + 0
-                return torch.compile(caller, backend="aot_eager", fullgraph=fullgraph)
+                return torch.compile(caller, backend=os.environ.get("RFA_TEST_COMPILE_BACKEND", "inductor"), fullgraph=fullgraph)
 
             # round 4: every schedule lowers to ONE registered operator per direction at any world size
             # (ring_flash_attn/_ops.py: rfa::sched_fwd / sched_bwd, rfa::llama3_fwd / llama3_bwd) —

@@ -43,9 +43,10 @@ def test_schedules_under_torch_compile_at_world_size_gt_1_on_the_hip_kernels(W, 
     """The reference runs every test a second time with the function under torch.compile at the full world size
     (/root/reference/test/test.sh:23-25, test/test_zigzag_ring_flash_attn_func.py:105-108).  GPU twin of
     tests/test_schedules_cpu.py::test_schedules_under_torch_compile_at_world_size_gt_1: W processes share the GPU, every
-    public function is called through a torch.compile'd caller (traced tensor work on both sides of the call; the
-    multi-rank schedule itself is a deliberate graph break) on the HIP kernels, and must reproduce the golden vectors of
-    the unmodified reference — both exchange forms of the zigzag path, and the other schedules."""
+    public function is called through a torch.compile'd caller — default (inductor) backend like the reference's tests,
+    `fullgraph=True`: traced tensor work on both sides of the call, the multi-rank schedule captured as ONE registered
+    operator per direction (rfa::sched_fwd / sched_bwd), no graph break — on the HIP kernels, and must reproduce the
+    golden vectors of the unmodified reference: both exchange forms of the zigzag path, and the other schedules."""
     import _ring_worker as RW
     import make_golden as MG
     from conftest import free_port

@@ -13,7 +13,7 @@ import torch
 
 from test_gpu_kernels import BF, _check, _dev, _grads_ok
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.extended]
 
 
 def _oracle(q, k, v, do, causal, window=(-1, -1), cu=None, drop=None):

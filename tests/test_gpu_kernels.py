@@ -305,6 +305,7 @@ def test_empty_problem_is_noop(single_rank_group):
     (1000, 488, True, 1, 4, 1),       # more queries than keys: bottom-right alignment leaves rows without keys
     (96, 4000, True, 1, 2, 2),        # one query block against 63 key tiles (deep dS ring)
 ])
+@pytest.mark.extended
 def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk):
     """The dS-spill backward through the backend (accumulate and plain outputs) against the CPU oracle and
     against the recompute backward on the same inputs (they share dK/dV bit for bit: same kernel, the spill
@@ -359,6 +360,7 @@ def test_ds_spill_backward_matches_oracle_and_recompute(Sq, Sk, causal, B, H, Hk
     (2, 640, 896, 6, 6, False, None),           # MHA, batch, rectangular rows, ragged tiles
     (3, 1100, 1100, 8, 4, True, [0, 300, 1400, 2100]),   # packed sequences
 ])
+@pytest.mark.extended
 def test_ds_handoff_in_head_group_chunks(B, Sq, Sk, H, Hk, causal, cu):
     """ABI 5: a dS scratch SMALLER than the whole hand-off does not switch the 5-GEMM backward off — the call runs it in
     head-group chunks over the one buffer (include/rfa.h: ds_scratch_bytes): chunks of whole K/V heads, then fractions
@@ -435,6 +437,7 @@ def test_ds_handoff_in_head_group_chunks(B, Sq, Sk, H, Hk, causal, cu):
     (512, 1024, False, 1, 2, 2),      # ring "front" step shape
     (96, 300, True, 1, 2, 2),         # fewer tiles (2) than splits
 ])
+@pytest.mark.extended
 def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, causal, B, H, Hk):
     """The 256-key dK/dV kernel form (csrc/rfa_bwd.hip kWide), forced onto small shapes with every split count
     (RFA_DKDV_NSPLIT; production picks it from the shapes): plain io outputs, fp32 accumulate (+=), fp32
@@ -504,6 +507,7 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
                 _check(f"nsplit={nsplit} spill={spill} {mode}.{n} vs 128-key form", a_, b_.float(), 0, kind="grad")
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("causal", [True, False])
 def test_ds_spill_packed_sequences_with_longer_keys(monkeypatch, causal):
     """dS-spill backward on packed sequences whose K/V are longer than Q (the llama3 shape: local queries against
@@ -574,6 +578,7 @@ def test_torch_compile_fullgraph_on_gpu(single_rank_group):
     (640, 640, 64, True, (100, 0)),         # head dim 64 instances
     (512, 512, 128, False, (0, 0)),         # one-key band (diagonal)
 ])
+@pytest.mark.extended
 def test_sliding_window_kernels_match_oracle(Sq, Sk, D, causal, window):
     """window_left / window_right of rfa_fwd / rfa_bwd (flash_attn semantics; forwarded by the reference's llama3
     path and HF adapter) against the CPU oracle: forward, backward (plain and fp32-accumulate outputs)."""
@@ -607,6 +612,7 @@ def test_sliding_window_kernels_match_oracle(Sq, Sk, D, causal, window):
     _grads_ok("window", (dq, dk, dv), (rdq, rdk, rdv))
 
 
+@pytest.mark.extended
 def test_sliding_window_varlen_and_llama3_single_rank(single_rank_group):
     """packed sequences + window through the public API (llama3 entry point, world size 1)"""
     import ring_flash_attn as R
@@ -639,6 +645,7 @@ def test_sliding_window_varlen_and_llama3_single_rank(single_rank_group):
     (64, 4, 1, 512, 512, False, BF),          # head-dim-64 instances, no mask
     (96, 2, 2, 260, 260, True, torch.float16),   # padded head dim (register staging), fp16
 ])
+@pytest.mark.extended
 def test_dropout_dense_matches_oracle(D, H, Hk, Sq, Sk, causal, dtype):
     from oracle import flash_attn_ref as O
     from ring_flash_attn.backend import get_backend
@@ -680,6 +687,7 @@ def test_dropout_dense_matches_oracle(D, H, Hk, Sq, Sk, causal, dtype):
         assert d <= 1.6e-2 * out.float().abs().max().item(), f"offset call differs from the full call by {d:.3e}"
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("cu", [[0, 128, 1248, 2001], [0, 3, 70, 71, 600]])
 def test_dropout_varlen_public_api_matches_oracle(single_rank_group, cu):
     """packed sequences starting at positions that are not multiples of 4 (the mask words then straddle the lanes' key
@@ -710,6 +718,7 @@ def test_dropout_varlen_public_api_matches_oracle(single_rank_group, cu):
     _grads_ok("drop.varlen", (qd.grad, kd.grad, vd.grad), (rdq, rdk, rdv))
 
 
+@pytest.mark.extended
 @pytest.mark.parametrize("W,stride", [(2, 1), (4, 2)])
 def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
     """llama3 over W ranks sharing the GPU, dropout on: every rank / head group draws the bits of the unsharded call"""
@@ -751,6 +760,7 @@ def test_llama3_dropout_hip_matches_single_device_oracle(W, stride):
     (2, 300, 520, 4, 4, 72, False, BF),
     (1, 96, 4000, 2, 2, 96, True, BF),               # one query block against 63 key tiles
 ])
+@pytest.mark.extended
 def test_head_dims_65_to_96_match_oracle(B, Sq, Sk, H, Hk, D, causal, dtype):
     """forward (plain and merged into fp32 accumulators) and backward (plain and += outputs) of the three-block instances
     against the CPU oracle; packed (cu_seqlens) input through the same instances"""
@@ -822,6 +832,7 @@ def test_head_dims_65_to_96_match_oracle(B, Sq, Sk, H, Hk, D, causal, dtype):
     (1, 900, 260, 2, 2, 128, True, torch.float16),   # queries without any visible key (lse = +inf), fp16 MFMAs
     (1, 1500, 1500, 4, 4, 64, True, BF),             # head dim 64 instance
 ])
+@pytest.mark.extended
 def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq, Sk, H, Hk, D, causal, dtype):
     """both forward forms on grids below the threshold: against the oracle, and against each other BIT FOR BIT (a wave's
     32 rows do not depend on how many waves share its workgroup) — plain outputs and the fused merge epilogue"""
@@ -863,6 +874,7 @@ def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq
     (1, 300, 1000, 2, 1, 64, False, "8"),        # head dim 64; more shares than tile pairs: empty shares
     (1, 700, 520, 2, 2, 128, True, "2"),         # more queries than keys: rows without any key (lse = +inf)
 ])
+@pytest.mark.extended
 def test_fwd_split_kv_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, D, causal, nsplit):
     """ABI 5 split-KV forward launches: the key tiles of a workgroup divided between several workgroups, normalised
     partials in a workspace, a combine pass — against the oracle and against the unsplit launch, plain outputs and the
@@ -912,6 +924,7 @@ def test_fwd_split_kv_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, D, causal, n
     assert (res[nsplit][1] - res["1"][1])[torch.isfinite(res["1"][1])].abs().max().item() < 1e-5
 
 
+@pytest.mark.extended
 def test_fwd_split_kv_packed_sequences(single_rank_group, monkeypatch):
     """split-KV over packed sequences of very different lengths (shares that are empty for the short sequences) through the
     public varlen API, single-rank; and the llama3 path whose long gathered key ranges are what the form is for"""
@@ -937,6 +950,7 @@ def test_fwd_split_kv_packed_sequences(single_rank_group, monkeypatch):
         _grads_ok(f"varlen.split{mode}", (qd.grad, kd.grad, vd.grad), (rdq, rdk, rdv))
 
 
+@pytest.mark.extended
 def test_fwd_128_row_form_in_the_schedules(single_rank_group, monkeypatch):
     """packed sequences, half-sequence selectors and the fused fp32 merge epilogue: the zigzag varlen schedule forced
     onto its multi-step path (_testing.force_steps) with the library's choice of the forward form (128 rows on this

@@ -297,8 +297,9 @@ def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
 @pytest.mark.parametrize("W", [2, 4])
 def test_schedules_under_torch_compile_at_world_size_gt_1(W, monkeypatch):
     """the reference's second test pass (test/test.sh:23-25: every test again with the function compiled, at the full
-    world size).  Multi-rank schedules are graph breaks by design (`torch.compiler.disable`); a compiled caller
-    must reproduce the golden vectors AND the plain call bit for bit — for both exchange forms of the zigzag path."""
+    world size; default backend = inductor, as there).  A multi-rank schedule is captured as ONE registered operator per
+    direction (`fullgraph=True`: no graph break); a compiled caller must reproduce the golden vectors AND the plain
+    call bit for bit — for both exchange forms of the zigzag path."""
     monkeypatch.setenv("RFA_TEST_COMPILE", "1")
     names = [n for n, c in MG.CASES.items() if c["W"] == W and "sample" not in c]
     assert names
