@@ -32,7 +32,12 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    items.sort(key=lambda it: 1 if it.get_closest_marker("extended") else 0)      # stable: core first, file order kept
+    def tier(it):
+        if not it.get_closest_marker("extended"):
+            return 0
+        return 1 if "at_its_stated_depth" in it.name else 2       # BASELINE config 5 at full depth opens the second tier
+
+    items.sort(key=tier)                                          # stable: core first, file order kept inside a tier
 
 
 def pytest_runtest_setup(item):
