@@ -54,3 +54,5 @@ for f in sorted(glob.glob("$OUT/${TAG}_bench_n${N}*.json")):
         print(f, "unreadable:", e)
 PY
 tail -20 $OUT/${TAG}_overlap_n${N}.txt
+# the raw trace (hundreds of MB with --hip-trace) is scratch: gpurun merges at most 64 MiB of gpurun_out/ back
+[ "${KEEP_TRACE:-0}" = "1" ] || rm -rf $OUT/trace

@@ -1,0 +1,192 @@
+// mfma_power_probe.hip — what bf16 MFMA rate does an MI355X sustain at its POWER cap, as a function of the operand data?
+// Stand-alone (no torch):   hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o /tmp/mfma_power_probe -lpthread
+//
+// Round-5 finding (tools/power_probe.py): the board sits at its 1400 W cap during the dK/dV kernel, the dQ kernel, the
+// whole backward and the whole fwd + bwd step — the step's time is its ENERGY divided by 1400 W, not a cycle count at the
+// nominal 2.4 GHz.  The 2.5 PFLOP/s peak bench.py prices `roofline.frac` against is the datasheet's (and the guide's
+// micro-benchmark's, whose operands are constants); the rate the chip can PAY FOR on random operands is lower.  This probe
+// measures it: a register-only kernel — per wave kAcc independent accumulators, back-to-back v_mfma_f32_32x32x16_bf16, no
+// LDS, no memory traffic in the loop — on 256 CUs x 1 or 2 waves per SIMD, with operands that are
+//     zero            all-zero A and B (no toggling: the best case)
+//     const           one constant pattern re-used by every MFMA (the usual micro-benchmark)
+//     random          a fresh pseudo-random bf16 operand pair per MFMA, rotated through 8 register pairs (N(0,1)-like
+//                     magnitudes: what an attention kernel's Q / K / P / dO fragments look like to the matrix pipe)
+// while a thread samples the hwmon power of the GPUs (microwatts, the maximum over the cards = the one in use).  Prints
+// TFLOP/s, average watts and pJ per FLOP (after subtracting the idle floor measured first) per configuration.
+#include <hip/hip_runtime.h>
+#include <dirent.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
+#include <chrono>
+#include <string>
+#include <thread>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int kAcc = 4;        // independent accumulators per wave (64 accumulator registers)
+constexpr int kOps = 8;        // operand register pairs rotated through
+
+// mode 0 zero, 1 const, 2 random
+template <int kMode>
+__global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float* sink, int iters) {
+  const int tid = threadIdx.x + blockIdx.x * blockDim.x;
+  bf16x8 a[kOps], b[kOps];
+  uint32_t s = seed[tid & 1023] * 2654435761u + tid;
+#pragma unroll
+  for (int i = 0; i < kOps; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = 0.f, y = 0.f;
+      if (kMode == 1) { x = 0.37f; y = -0.81f; }
+      if (kMode == 2) {
+        s = s * 1664525u + 1013904223u;
+        x = ((int)(s >> 8) % 4001 - 2000) * 0.001f;       // uniform in [-2, 2]: every mantissa / exponent bit toggles
+        s = s * 1664525u + 1013904223u;
+        y = ((int)(s >> 8) % 4001 - 2000) * 0.001f;
+      }
+      a[i][e] = (__bf16)x;
+      b[i][e] = (__bf16)y;
+    }
+  f32x16 acc[kAcc];
+#pragma unroll
+  for (int i = 0; i < kAcc; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+      acc[i % kAcc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % kOps], b[(i / 2) % kOps], acc[i % kAcc], 0, 0, 0);
+    if (kMode == 2 && (it & 63) == 63) {
+      // keep the accumulators bounded (random products random-walk): fold them back, off the hot path
+#pragma unroll
+      for (int i = 0; i < kAcc; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] *= 0.0009765625f;
+    }
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < kAcc; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[i][r];
+  if (t == 12345.678f) sink[tid] = t;       // (never true: keeps the loop alive)
+}
+
+static std::vector<std::string> power_files() {
+  std::vector<std::string> out;
+  for (int card = 0; card < 128; ++card)
+    for (int hw = 0; hw < 64; ++hw) {
+      char p[256];
+      snprintf(p, sizeof p, "/sys/class/drm/card%d/device/hwmon/hwmon%d/power1_input", card, hw);
+      FILE* f = fopen(p, "r");
+      if (!f) {
+        snprintf(p, sizeof p, "/sys/class/drm/card%d/device/hwmon/hwmon%d/power1_average", card, hw);
+        f = fopen(p, "r");
+      }
+      if (f) {
+        fclose(f);
+        out.push_back(p);
+      }
+    }
+  return out;
+}
+
+static double read_watts(const std::vector<std::string>& files) {
+  double best = -1;
+  for (auto& p : files) {
+    FILE* f = fopen(p.c_str(), "r");
+    if (!f) continue;
+    long long uw = 0;
+    if (fscanf(f, "%lld", &uw) == 1 && uw / 1e6 > best) best = uw / 1e6;
+    fclose(f);
+  }
+  return best;
+}
+
+struct Sampler {
+  std::vector<std::string> files = power_files();
+  std::atomic<bool> on{false}, quit{false};
+  double sum = 0, peak = 0;
+  long n = 0;
+  std::thread th;
+  Sampler() {
+    th = std::thread([this] {
+      while (!quit) {
+        if (on) {
+          double w = read_watts(files);
+          if (w >= 0) { sum += w; n++; if (w > peak) peak = w; }
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+      }
+    });
+  }
+  void start() { sum = 0; peak = 0; n = 0; on = true; }
+  double stop() { on = false; std::this_thread::sleep_for(std::chrono::milliseconds(20)); return n ? sum / n : -1; }
+  ~Sampler() { quit = true; th.join(); }
+};
+
+template <int kMode>
+static void run(const char* name, int waves_per_simd, double seconds, const uint32_t* seed, float* sink, Sampler& smp, double idle_w) {
+  const int threads = waves_per_simd == 2 ? 512 : 256, blocks = 256;
+  const double flop_per_iter = 32.0 * 32 * 32 * 16 * 2;       // per wave and loop iteration
+  const int waves = blocks * threads / 64;
+  int iters = 2000;
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  // warm + size
+  hipLaunchKernelGGL(mfma_loop<kMode>, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL(mfma_loop<kMode>, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const int launches = (int)(seconds * 1e3 / ms) + 1;
+  // ramp (untimed), then the measured window
+  for (int i = 0; i < launches / 3 + 1; ++i) hipLaunchKernelGGL(mfma_loop<kMode>, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters);
+  CHECK(hipDeviceSynchronize());
+  smp.start();
+  CHECK(hipEventRecord(e0));
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(mfma_loop<kMode>, dim3(blocks), dim3(threads), 0, 0, seed, sink, iters);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  const double w = smp.stop();
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = flop_per_iter * iters * (double)waves * launches;
+  const double tf = flops / (ms * 1e-3) / 1e12;
+  printf("%-8s %d wave(s)/SIMD: %8.1f TFLOP/s  %7.1f W avg  %7.1f W peak  %6.3f pJ/FLOP all-in  %6.3f pJ/FLOP above the %.0f W floor  (%ld samples)\n",
+         name, waves_per_simd, tf, w, smp.peak, w / (tf * 1e12) * 1e12, (w - idle_w) / (tf * 1e12) * 1e12, idle_w, smp.n);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
+  Sampler smp;
+  printf("power files: %zu\n", smp.files.size());
+  std::vector<uint32_t> h(1024);
+  for (int i = 0; i < 1024; ++i) h[i] = 0x9E3779B9u * (i + 1);
+  uint32_t* seed;
+  float* sink;
+  CHECK(hipMalloc(&seed, 4096));
+  CHECK(hipMalloc(&sink, 256 * 512 * 4));
+  CHECK(hipMemcpy(seed, h.data(), 4096, hipMemcpyHostToDevice));
+  std::this_thread::sleep_for(std::chrono::milliseconds(1500));
+  smp.start();
+  std::this_thread::sleep_for(std::chrono::milliseconds(1000));
+  const double idle_w = smp.stop();
+  printf("idle floor: %.1f W\n", idle_w);
+  for (int wps = 1; wps <= 2; ++wps) {
+    run<0>("zero", wps, seconds, seed, sink, smp, idle_w);
+    run<1>("const", wps, seconds, seed, sink, smp, idle_w);
+    run<2>("random", wps, seconds, seed, sink, smp, idle_w);
+  }
+  return 0;
+}
