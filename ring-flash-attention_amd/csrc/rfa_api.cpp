@@ -249,7 +249,7 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 
 // Which dK/dV kernel form a call runs — a pure function of the call's arguments (shapes + the dkdv_form /
 // dkdv_nsplit fields), so that rfa_bwd_workspace_bytes, a BWD_COMPUTE and its BWD_REDUCE call agree: the 256-key
-// workgroup form needs head dim 128 and no window; its workgroups are B * Hk * ceil(Sk / 256), so the Q/dO tile
+// workgroup form needs head dim 128 or 64 (exactly) and no window; its workgroups are B * Hk * ceil(Sk / 256), so the Q/dO tile
 // range of a key block is shared by up to 4 workgroups until the launch has about two workgroups per CU (a causal
 // launch needs that many for its heavy-first order to balance), each with at least 8 tiles.  Launches that stay
 // small even so run the 128-key form (twice the workgroups).
@@ -276,7 +276,7 @@ static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
     return pl;
   }
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-  if (a->dkdv_form == RFA_DKDV_128 || a->D != kHeadDim || win || a->dropout_p > 0.f) return pl;
+  if (a->dkdv_form == RFA_DKDV_128 || (a->D != kHeadDim && a->D != 64) || win || a->dropout_p > 0.f) return pl;
   const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
   // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) key blocks per K/V head, of which
   // only about total_k / 256 (+ one tail per sequence) are not past the end of their sequence

@@ -402,7 +402,7 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 
 // kD: compiled head dim (128 / 64); kFullD: D == kD (LDS-DMA staging) else zero padded (register staging);
 // kSpill: store dS for rfa_dqs.hip (kD = 128 only)
-// kWide: the workgroup owns 256 keys = 8 key blocks, wave w runs BOTH sub-tiles of every Q/dO tile for key
+// kWide (head dim 128, and — round 5 — 64): the workgroup owns 256 keys = 8 key blocks, wave w runs BOTH sub-tiles of every Q/dO tile for key
 // block w.  Same registers per wave as the parity form (one sub-tile is live at a time), same LDS (the V rows
 // take the space the final parity exchange used), but every staged Q/dO tile now feeds twice the MFMAs: the
 // LDS-DMA pieces per MFMA are halved (measured: dropping half of the pieces is worth 15 % of the kernel),
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   static_assert(!kSpill || (kD == 128 && !kWin), "the dS spill path: head dim 128, no window");
-  static_assert(!kWide || (kD == 128 && kFullD && !kWin), "the 256-key form: head dim 128, no window");
+  static_assert(!kWide || ((kD == 128 || kD == 64) && kFullD && !kWin), "the 256-key form: head dim 128 / 64 exactly, no window");
   static_assert(!kDrop || (!kSpill && !kWin && !kWide), "dropout: the plain 128-key instances");
   constexpr int kKeys = kWide ? 2 * kKvKeys : kKvKeys;       // keys per workgroup
   typedef HeadGeo<kD> Geo;
@@ -994,7 +994,10 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
   if (p.drop_keep < 256)                          // rfa_api.cpp: dropout calls run the 128-key form without spill / window
     return dtype == 0 ? launch_dkdv_d<bf16_t, false, true>(p, stream) : launch_dkdv_d<f16_t, false, true>(p, stream);
-  if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 without a window
+  if (p.wide && p.D == 64)                        // round 5: the 256-key form for head dim 64 (7-GEMM backward: no dS hand-off there)
+    return dtype == 0 ? launch_dkdv_t<bf16_t, 64, true, false, false, true>(p, stream)
+                      : launch_dkdv_t<f16_t, 64, true, false, false, true>(p, stream);
+  if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 / 64 without a window
     if (p.ds != nullptr)
       return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true>(p, stream)
                         : launch_dkdv_t<f16_t, 128, true, true, false, true>(p, stream);

@@ -267,10 +267,15 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_COMPUTE)) == ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_REDUCE))
     # ring "front" step of world size 8 (all queries x 4096 keys): four workgroups per key block
     assert ws(args(1, 8192, 4096, 32, 8)) == 4 * unit32(4096, 8)
-    # small launches, head dim 64 and windows keep the 128-key form (no split, no workspace)
+    # small launches, padded head dims and windows keep the 128-key form (no split, no workspace)
     assert plan(args(1, 1024, 1024, 4, 2)) == (_C.DKDV_128, 1)
     assert ws(args(1, 1024, 1024, 4, 2)) == 0
-    assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert ws(args(1, 8192, 8192, 32, 8, D=96)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=96)) == 0
+    assert plan(args(1, 8192, 8192, 32, 8, D=56, causal=True)) == (_C.DKDV_128, 1)
+    # head dim 64 exactly (round 5): the 256-key form by the same shape rules, never a dS hand-off
+    assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == (_C.DKDV_256, 2)
+    assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 2 * unit32(8192, 8, 64) and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert plan(args(1, 1024, 1024, 4, 2, D=64)) == (_C.DKDV_128, 1)
     assert ws(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0 and ds(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0
     # packed sequences: the form is chosen from the packed row count, and so is the scratch (ABI 5): total / 32 + B
     # query-block rows per head, each with the key blocks of the longest (half) sequence — 3.9 GB for the varlen

@@ -437,12 +437,13 @@ def test_ds_handoff_in_head_group_chunks(B, Sq, Sk, H, Hk, causal, cu):
     (512, 1024, False, 1, 2, 2),      # ring "front" step shape
     (96, 300, True, 1, 2, 2),         # fewer tiles (2) than splits
 ])
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.extended
-def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, causal, B, H, Hk):
-    """The 256-key dK/dV kernel form (csrc/rfa_bwd.hip kWide), forced onto small shapes with every split count
-    (RFA_DKDV_NSPLIT; production picks it from the shapes): plain io outputs, fp32 accumulate (+=), fp32
-    overwrite slots, two-phase COMPUTE / REDUCE — with and without the dS spill — against the CPU oracle, and
-    against the 128-key form on the same inputs."""
+def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, causal, B, H, Hk, D):
+    """The 256-key dK/dV kernel form (csrc/rfa_bwd.hip kWide; head dim 128 and — round 5 — 64), forced onto small shapes
+    with every split count (RFA_DKDV_NSPLIT; production picks it from the shapes): plain io outputs, fp32 accumulate (+=),
+    fp32 overwrite slots, two-phase COMPUTE / REDUCE — with and without the dS spill (head dim 64 has no hand-off: it
+    runs its 7-GEMM form) — against the CPU oracle, and against the 128-key form on the same inputs."""
     from oracle import flash_attn_ref as O
     from ring_flash_attn import _C
     from ring_flash_attn.backend import get_backend
@@ -452,11 +453,11 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
     be = get_backend()
     dev = _dev()
     g = torch.Generator().manual_seed(11)
-    q = torch.randn(B, Sq, H, 128, generator=g).to(BF)
-    k = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
-    v = torch.randn(B, Sk, Hk, 128, generator=g).to(BF)
-    do = torch.randn(B, Sq, H, 128, generator=g).to(BF)
-    scale = 128 ** -0.5
+    q = torch.randn(B, Sq, H, D, generator=g).to(BF)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(BF)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(BF)
+    do = torch.randn(B, Sq, H, D, generator=g).to(BF)
+    scale = D ** -0.5
     ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, causal)
     rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, causal)
@@ -473,8 +474,8 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
         dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
         be.bwd(dod, qd, kd, vd, lse, delta, dq=dq, dk=dk, dv=dv, **kw)
         res["plain"] = (dq, dk, dv)
-        dqa = torch.zeros((B, Sq, H, 128), dtype=torch.float32, device=dev)
-        dka = torch.full((B, Sk, Hk, 128), 2.0, dtype=torch.float32, device=dev)
+        dqa = torch.zeros((B, Sq, H, D), dtype=torch.float32, device=dev)
+        dka = torch.full((B, Sk, Hk, D), 2.0, dtype=torch.float32, device=dev)
         dva = torch.full_like(dka, -1.0)
         be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, **kw)          # += (workspace)
         res["acc"] = (dqa, dka - 2.0, dva + 1.0)
@@ -498,7 +499,7 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
     narrow = run_all()
     monkeypatch.setenv("RFA_DKDV_WIDE", "1")
     monkeypatch.setenv("RFA_DKDV_NSPLIT", nsplit)
-    for spill in ("1", "0"):
+    for spill in ("1", "0") if D > 64 else ("1",):
         monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
         wide = run_all()
         for mode, got in wide.items():
@@ -568,6 +569,56 @@ def test_torch_compile_fullgraph_on_gpu(single_rank_group):
     oc.backward(do)
     assert torch.equal(oc, oe) and torch.equal(lc, le) and torch.equal(xc.grad, xe.grad)
     torch._dynamo.reset()
+
+
+@pytest.mark.parametrize("shape", ["dense_5gemm", "dense_small_batch", "varlen"])
+def test_step_under_hip_graph_capture(single_rank_group, shape):
+    """a forward + backward of the single-rank step CAPTURED into a HIP graph
+    (torch.cuda.graph: allocations from the graph's pool, every launch on the capturing stream) and replayed — the
+    answer for launch-bound inner loops (B x S of a few thousand tokens: five 10-100 us kernels per step).  The library
+    is capture-safe by construction: it launches only on the stream it is given, never synchronises, and its reusable
+    dS scratch / workspaces are ordinary torch allocations of the capturing stream.  Replays on NEW data must reproduce
+    the eager result bit for bit — the 5-GEMM backward with its dS hand-off, the split dK/dV plan with its reduction pass,
+    packed sequences."""
+    import ring_flash_attn as R
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    if shape == "varlen":
+        cu = torch.tensor([0, 300, 1324, 2048], dtype=torch.int32, device=dev)
+        mk = lambda: (torch.randn(2048, 8, 128, generator=g).to(BF).to(dev), torch.randn(2048, 2, 2, 128, generator=g).to(BF).to(dev),
+                      torch.randn(2048, 8, 128, generator=g).to(BF).to(dev))
+        fn = lambda q, kv: R.zigzag_ring_flash_attn_varlen_kvpacked_func(q, kv, cu, 1024, causal=True)
+    else:
+        B, S = (1, 2048) if shape == "dense_5gemm" else (8, 512)
+        mk = lambda: (torch.randn(B, S, 8, 128, generator=g).to(BF).to(dev), torch.randn(B, S, 2, 2, 128, generator=g).to(BF).to(dev),
+                      torch.randn(B, S, 8, 128, generator=g).to(BF).to(dev))
+        fn = lambda q, kv: R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+    q0, kv0, do0 = mk()
+    sq, skv, sdo = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True), do0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up off the default stream, as torch's capture recipe asks
+        for _ in range(3):
+            sq.grad = skv.grad = None
+            fn(sq, skv).backward(sdo)
+    torch.cuda.current_stream().wait_stream(side)
+    sq.grad = skv.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        sout = fn(sq, skv)
+        sout.backward(sdo)
+    for trial in range(2):                             # replays on fresh inputs
+        q1, kv1, do1 = mk()
+        with torch.no_grad():
+            sq.copy_(q1); skv.copy_(kv1); sdo.copy_(do1)
+        graph.replay()
+        torch.cuda.synchronize()
+        eq, ekv = q1.clone().requires_grad_(True), kv1.clone().requires_grad_(True)
+        eout = fn(eq, ekv)
+        eout.backward(do1)
+        assert torch.equal(sout, eout), f"{shape}: out differs on replay {trial}"
+        assert torch.equal(sq.grad, eq.grad) and torch.equal(skv.grad, ekv.grad), f"{shape}: gradients differ on replay {trial}"
 
 
 @pytest.mark.parametrize("Sq,Sk,D,causal,window", [
