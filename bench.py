@@ -155,6 +155,60 @@ def committed_traffic(kernel, hk):
     return sect[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
 
 
+# Round 5 (profiles/r05_mfma_power_probe.txt, r05_power_probe.json): the board sits at its 1400 W cap during the
+# backward and the whole step, and a register-only MFMA loop sustains 2.46 PFLOP/s on zero / constant operands but
+# 1.83 PFLOP/s on random ones — the rate the chip can pay for depends on the data.  `roofline.peak` stays the datasheet's
+# 2.5 PFLOP/s (MI355X_MICROARCH.md); the line additionally quotes the fraction of this MEASURED random-operand rate.
+MFMA_RANDOM_DATA_TFLOPS = 1830.0
+
+
+class PowerSampler:
+    """board power beside the timed region (amdgpu hwmon power1_input / power1_average, microwatts; the maximum over the
+    cards of the node = the one in use on a one-GPU box): a thread that reads the files every 10 ms.  The sensor is a
+    moving average over about a second, so the figure is meaningful for timed regions of a few hundred ms and more;
+    None where the files do not exist."""
+
+    def __init__(self):
+        import glob
+        import threading
+
+        self.files = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            for name in ("power1_input", "power1_average"):
+                if os.path.exists(os.path.join(hw, name)):
+                    self.files.append(os.path.join(hw, name))
+                    break
+        self.samples, self._on, self._quit = [], False, False
+        self._th = threading.Thread(target=self._run, daemon=True)
+        if self.files:
+            self._th.start()
+
+    def _run(self):
+        while not self._quit:
+            if self._on:
+                best = None
+                for f in self.files:
+                    try:
+                        w = int(open(f).read()) / 1e6
+                        best = w if best is None or w > best else best
+                    except Exception:
+                        pass
+                if best is not None:
+                    self.samples.append(best)
+            time.sleep(0.01)
+
+    def start(self):
+        self.samples, self._on = [], True
+
+    def stop(self):
+        self._on = False
+        s = self.samples
+        return (sum(s) / len(s), max(s), len(s)) if s else (None, None, 0)
+
+    def close(self):
+        self._quit = True
+
+
 class _Hip:
     """the few HIP runtime calls the in-step timer needs (raw events: the C ABI takes hipEvent_t handles)"""
 
@@ -705,7 +759,13 @@ def main():
         step()
     counter[0] = 0
     torch.cuda.reset_peak_memory_stats(dev)
+    power = PowerSampler() if rank == 0 else None
+    if power:
+        power.start()
     elapsed = timed(args.steps)
+    watts = power.stop() if power else (None, None, 0)
+    if power:
+        power.close()
     # peak device memory of the timed steps (the reference names memory as its known limitation, README.md:154; the
     # gather exchange form trades O(S_total) scratch for fewer transfers): allocator peak incl. the inputs, max over ranks
     peak = torch.tensor([float(torch.cuda.max_memory_allocated(dev))], dtype=torch.float64, device=dev if multi else "cpu")
@@ -744,6 +804,11 @@ def main():
             "forward_only": fwd_only,
         },
         "peak_device_memory_gib": round(peak_gib, 3),
+        # board power over the timed region (hwmon, a ~1 s moving average: meaningful from a few hundred ms of steps on)
+        # and the energy of one step: at the 1400 W cap the step's time IS its energy / 1400 W
+        "power": ({"avg_w": round(watts[0], 1), "max_w": round(watts[1], 1), "samples": watts[2],
+                   "joules_per_step": round(watts[0] * elapsed / args.steps, 4), "source": "amdgpu hwmon power1_input"}
+                  if watts[0] is not None else None),
         "algorithmic_tflops_per_gpu": per_gpu_flops * its / 1e12,
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
     }
@@ -912,6 +977,10 @@ def main():
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / MFMA_PEAK_TFLOPS,
+                # against the rate a register-only MFMA loop sustains on RANDOM operands on this chip (measured:
+                # tools/mfma_power_probe.hip, profiles/r05_mfma_power_probe.txt; 2.46 PFLOP/s on zero / constant operands)
+                "frac_of_random_operand_mfma_rate": ach / MFMA_RANDOM_DATA_TFLOPS,
+                "random_operand_mfma_tflops": MFMA_RANDOM_DATA_TFLOPS,
                 "traffic": entry["hbm_bytes_per_launch"] if entry else None,
                 "traffic_algorithmic": entry.get("algorithmic_bytes") if entry else None,
                 "traffic_handoff": entry.get("handoff_bytes") if entry else None,

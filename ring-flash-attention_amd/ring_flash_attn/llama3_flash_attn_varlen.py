@@ -28,7 +28,7 @@ from . import config
 from .backend import get_backend
 from .utils import AllGatherComm as Comm, group_rank_world, reduce_scatter_async, single_rank
 from ._api import _check_unsupported, _opaque
-from ._common import _as_cu, dropout_arg, draw_dropout_seed
+from ._common import _as_cu, dropout_arg, draw_dropout_seed, packed_pair
 
 
 def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world: int, head_dim: int,
@@ -132,6 +132,19 @@ def llama3_flash_attn_varlen_forward(
         return out, lse
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
+    kvp = packed_pair(k, v) if hs == nheads_k else None
+    if kvp is not None:
+        # k and v are the two halves of ONE packed (T, 2, Hk, D) tensor (the kvpacked / qkvpacked entry points) and all
+        # heads are one super-group: the packed tensor travels as it is — ONE all-gather instead of two, no contiguous
+        # copies of the halves (round 5: those were 2 of the elementwise launches per pass of
+        # profiles/r04_short_launch_kernel_trace.txt); the gathered K / V are strided views of the one buffer
+        buf = torch.empty((total_k * world_size,) + tuple(kvp.shape[1:]), dtype=k.dtype, device=k.device)
+        comm = Comm(process_group)
+        comm.all_gather(buf, kvp)
+        comm.wait()
+        be.fwd(q, buf[local_k_slice, 0], buf[local_k_slice, 1], softmax_scale=softmax_scale, causal=causal,
+               out=out, lse=lse, window=window_size, dropout=drop(0), **vl)
+        return out, lse
     groups = list(range(0, nheads_k, hs))
     bufs = [torch.empty((2, total_k * world_size, hs, head_dim), dtype=k.dtype, device=k.device)
             for _ in range(min(2, len(groups)))]
@@ -219,9 +232,35 @@ def llama3_flash_attn_varlen_backward(
         return dq, dk, dv
 
     hs = fused_heads_k_stride(nheads_k, heads_k_stride, total_k, world_size, head_dim, k.element_size())
+    rows_all = total_k * world_size
+    kvp = packed_pair(k, v) if hs == nheads_k else None
+    if kvp is not None:
+        # packed kv, one super-group (see the forward): ONE all-gather of the packed tensor, the dK/dV kernel writes this
+        # rank's contributions into the two halves of ONE packed (rows, 2, Hk, D) buffer, and ONE reduce-scatter lands
+        # them — in the packed gradient itself when the caller handed one over (the kvpacked entry points): no second
+        # collective, no copy-back
+        lo, hi = local_k_slice.start or 0, local_k_slice.stop if local_k_slice.stop is not None else rows_all
+        buf = torch.empty((rows_all,) + tuple(kvp.shape[1:]), dtype=k.dtype, device=k.device)
+        comm = Comm(process_group)
+        comm.all_gather(buf, kvp)
+        dkvc = torch.empty_like(buf)
+        if lo > 0:
+            dkvc[:lo].zero_()
+        if hi < rows_all:
+            dkvc[hi:].zero_()
+        comm.wait()
+        be.bwd(dout, q, buf[local_k_slice, 0], buf[local_k_slice, 1], softmax_lse, delta, softmax_scale=softmax_scale,
+               causal=causal, dq=dq, dk=dkvc[local_k_slice, 0], dv=dkvc[local_k_slice, 1], deterministic=deterministic,
+               window=window_size, dropout=drop(0), **vl)
+        dst = packed_pair(dk, dv)
+        land = dst if dst is not None else torch.empty((total_k,) + tuple(kvp.shape[1:]), dtype=k.dtype, device=k.device)
+        reduce_scatter_async(land, dkvc, group=process_group).wait()
+        if dst is None:
+            dk.copy_(land[:, 0])
+            dv.copy_(land[:, 1])
+        return dq, dk, dv
     groups = list(range(0, nheads_k, hs))
     nbuf = min(2, len(groups))
-    rows_all = total_k * world_size
     kv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
     # this rank's dK/dV contributions for EVERY rank's rows (summed over ranks by the reduce-scatter)
     dkv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]

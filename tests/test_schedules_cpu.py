@@ -475,7 +475,26 @@ def _llama3_groups_rank(rank, W, port, ret):
         out.backward(do[sl])
         res[budget] = (out.detach(), lse.detach(), ql.grad, kl.grad, vl.grad)
     a, b = res["0"], res[str(1 << 30)]
-    ret[rank] = [i for i, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
+    bad = [i for i, (x, y) in enumerate(zip(a, b)) if not torch.equal(x, y)]
+    # the kvpacked / qkvpacked entry points: the packed tensor travels as ONE buffer (one all-gather, one reduce-scatter
+    # straight into the packed gradient) when all heads are one super-group — same bits again
+    kvl = torch.stack([k[sl], v[sl]], dim=1).clone().requires_grad_(True)
+    ql = q[sl].clone().requires_grad_(True)
+    out, lse, _ = R.llama3_flash_attn_varlen_kvpacked_func(ql, kvl, cq, ck, mq, mk, heads_k_stride=1, local_k_slice=ks,
+                                                           causal=True, return_attn_probs=True)
+    out.backward(do[sl])
+    c = (out.detach(), lse.detach(), ql.grad, kvl.grad[:, 0], kvl.grad[:, 1])
+    bad += [10 + i for i, (x, y) in enumerate(zip(c, b)) if not torch.equal(x, y)]
+    qkvl = torch.stack([q[sl][:, :Hk], k[sl], v[sl]], dim=1).clone().requires_grad_(True)      # (MHA-shaped qkv: H = Hk)
+    o3 = R.llama3_flash_attn_varlen_qkvpacked_func(qkvl, cq, ck, mq, mk, heads_k_stride=Hk, local_k_slice=ks, causal=True)
+    o3.backward(do[sl][:, :Hk])
+    q3, k3, v3 = (t[sl].clone().requires_grad_(True) for t in (q[:, :Hk], k, v))
+    o4 = R.llama3_flash_attn_varlen_func(q3, k3, v3, cq, ck, mq, mk, heads_k_stride=Hk, local_k_slice=ks, causal=True)
+    o4.backward(do[sl][:, :Hk])
+    d = (o3.detach(), qkvl.grad[:, 0], qkvl.grad[:, 1], qkvl.grad[:, 2])
+    e = (o4.detach(), q3.grad, k3.grad, v3.grad)
+    bad += [20 + i for i, (x, y) in enumerate(zip(d, e)) if not torch.equal(x, y)]
+    ret[rank] = bad
     dist.barrier()
     dist.destroy_process_group()
 

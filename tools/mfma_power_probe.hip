@@ -11,6 +11,8 @@
 //     const           one constant pattern re-used by every MFMA (the usual micro-benchmark)
 //     random          a fresh pseudo-random bf16 operand pair per MFMA, rotated through 8 register pairs (N(0,1)-like
 //                     magnitudes: what an attention kernel's Q / K / P / dO fragments look like to the matrix pipe)
+//     zero_rt         zeros LOADED at run time into the same 8 register pairs (control: the instruction stream and the
+//                     register allocation of `random`, the data of `zero` — separates the data from the code)
 // while a thread samples the hwmon power of the GPUs (microwatts, the maximum over the cards = the one in use).  Prints
 // TFLOP/s, average watts and pJ per FLOP (after subtracting the idle floor measured first) per configuration.
 #include <hip/hip_runtime.h>
@@ -32,7 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kAcc = 4;        // independent accumulators per wave (64 accumulator registers)
 constexpr int kOps = 8;        // operand register pairs rotated through
 
-// mode 0 zero, 1 const, 2 random
+// mode 0 zero, 1 const, 2 random, 3 zeros loaded at run time
 template <int kMode>
 __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float* sink, int iters) {
   const int tid = threadIdx.x + blockIdx.x * blockDim.x;
@@ -44,6 +46,10 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float*
     for (int e = 0; e < 8; ++e) {
       float x = 0.f, y = 0.f;
       if (kMode == 1) { x = 0.37f; y = -0.81f; }
+      if (kMode == 3) {                                    // seed[1024 ..] holds zeros: opaque to the compiler
+        x = __uint_as_float(seed[1024 + ((tid + 8 * i + e) & 1023)]);
+        y = __uint_as_float(seed[1024 + ((tid + 8 * i + e + 5) & 1023)]);
+      }
       if (kMode == 2) {
         s = s * 1664525u + 1013904223u;
         x = ((int)(s >> 8) % 4001 - 2000) * 0.001f;       // uniform in [-2, 2]: every mantissa / exponent bit toggles
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float*
 #pragma unroll
     for (int i = 0; i < 32; ++i)
       acc[i % kAcc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % kOps], b[(i / 2) % kOps], acc[i % kAcc], 0, 0, 0);
-    if (kMode == 2 && (it & 63) == 63) {
+    if ((kMode == 2 || kMode == 3) && (it & 63) == 63) {
       // keep the accumulators bounded (random products random-walk): fold them back, off the hot path
 #pragma unroll
       for (int i = 0; i < kAcc; ++i)
@@ -171,13 +177,13 @@ int main(int argc, char** argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
   Sampler smp;
   printf("power files: %zu\n", smp.files.size());
-  std::vector<uint32_t> h(1024);
+  std::vector<uint32_t> h(2048, 0u);
   for (int i = 0; i < 1024; ++i) h[i] = 0x9E3779B9u * (i + 1);
   uint32_t* seed;
   float* sink;
-  CHECK(hipMalloc(&seed, 4096));
+  CHECK(hipMalloc(&seed, 8192));
   CHECK(hipMalloc(&sink, 256 * 512 * 4));
-  CHECK(hipMemcpy(seed, h.data(), 4096, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(seed, h.data(), 8192, hipMemcpyHostToDevice));
   std::this_thread::sleep_for(std::chrono::milliseconds(1500));
   smp.start();
   std::this_thread::sleep_for(std::chrono::milliseconds(1000));
@@ -187,6 +193,7 @@ int main(int argc, char** argv) {
     run<0>("zero", wps, seconds, seed, sink, smp, idle_w);
     run<1>("const", wps, seconds, seed, sink, smp, idle_w);
     run<2>("random", wps, seconds, seed, sink, smp, idle_w);
+    run<3>("zero_rt", wps, seconds, seed, sink, smp, idle_w);
   }
   return 0;
 }
