@@ -97,11 +97,24 @@ const char* rfa_strerror(int status) {
 // chain of key tiles (>= 64: about 1 us each, walked one after the other) are split until the slots are filled, each
 // share keeping at least 32 tiles (measured: 16-tile shares lose to the combine pass — S = 2048 self-attention with 16
 // heads 0.042 -> 0.044 ms — while a llama3 head group at 2048 rows against 16384 gathered keys gains 14 %).
+// Round 5 (profiles/r05_small_launch_fwd_forms.txt): when the 256-row grid has about HALF a workgroup per CU (112 .. 192
+// workgroups) and every workgroup a long chain of key tiles (>= 128), TWO shares of 256-row workgroups — one 8-wave
+// workgroup per CU, each K/V tile staged once for 256 rows — beat the 128-row form split the same way (twice the
+// workgroups, each tile staged for 128 rows: twice the L2 -> LDS traffic per MFMA): a llama3 head group at 2048 rows
+// against 16384 gathered keys 0.280 -> 0.268 ms, against 8192 keys 0.155 -> 0.151.
+static bool fwd_split_256_rows(const rfa_fwd_args* a) {
+  if (a->fwd_form != RFA_FWD_AUTO || a->kv_nsplit != 0 || a->D != kHeadDim) return false;
+  const int64_t wgs8 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + 255) / 256);
+  const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
+  return wgs8 >= 112 && wgs8 <= 192 && tiles >= 128 && eff_len(a->Sq, a->q_half) > 1024;
+}
 static int fwd_kv_nsplit(const rfa_fwd_args* a) {
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if ((a->D != kHeadDim && a->D != kHeadDim / 2) || win || a->dropout_p > 0.f) return 1;
-  if (a->fwd_form != RFA_FWD_AUTO || a->kv_nsplit == 1 || a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return 1;
-  if (a->kv_nsplit > 1) return a->kv_nsplit > 8 ? 8 : a->kv_nsplit;
+  if (a->kv_nsplit == 1 || a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return 1;
+  if (a->kv_nsplit > 1) return a->kv_nsplit > 8 ? 8 : a->kv_nsplit;      // (forced: with any named form, round 5)
+  if (a->fwd_form != RFA_FWD_AUTO) return 1;
+  if (fwd_split_256_rows(a)) return 2;
   const int64_t wgs128 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + 127) / 128);
   const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
   if (wgs128 >= 384 || tiles < 64) return 1;
@@ -181,7 +194,8 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   CombineParams cb{};
   if (ns > 1) {
     if (!aligned16(a->workspace)) return RFA_ERR_ALIGN;
-    rows = 128;
+    // shares of 128-row workgroups — of 256-row ones by name, or by the round-5 rule above
+    rows = (a->fwd_form == RFA_FWD_8x32 || fwd_split_256_rows(a)) ? fwd_qrows_per_block() : 128;
     const int64_t rt = fwd_rows_total(a);
     // partial layout: out (ns, rows_total, H, D) fp32, lse (ns, [B,] H, rows) fp32 behind it — addressed by the kernel
     // through the accumulate-mode fields (the call's own accumulators, if any, are the combine kernel's business)
