@@ -11,9 +11,9 @@
 # other build) — and only THEN the kernel-trace pass runs, so that the bench line committed with the trace carries
 # `roofline.traffic` of its own build instead of "stale" (round-3 review).
 # Output: gpurun_out/prof/<pass>/...; summaries: gpurun_out/prof/<tag>_*.txt + <tag>_traffic.json
-#   usage: bash profiles/collect_pmc.sh r04        (then copy gpurun_out/prof/r04_* into profiles/)
+#   usage: bash profiles/collect_pmc.sh r05        (then copy gpurun_out/prof/r05_* into profiles/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof
@@ -41,3 +41,5 @@ cd $R
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH"; python profiles/summarize_rocpd.py $(find $OUT/kt -name "*_results.db" | head -1); grep '^{' $OUT/kt.log | tail -1; } > $OUT/${TAG}_bench_kernel_trace_stats.txt 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- $BENCH --kv-heads 32"; python profiles/summarize_rocpd.py $(find $OUT/kt_hk32 -name "*_results.db" | head -1); grep '^{' $OUT/kt_hk32.log | tail -1; } > $OUT/${TAG}_bench_kernel_trace_stats_hk32.txt 2>&1
 tail -5 $OUT/${TAG}_bench_kernel_trace_stats.txt; python -c "import json; d=json.load(open('$OUT/${TAG}_traffic.json')); print({k: (v.get('traffic_over_algorithmic'), v.get('effective_clock_ghz_profiled'), v.get('mfma_pipe_busy')) for k, v in d.items() if isinstance(v, dict) and 'fetch_kib' in v})"
+# the raw rocprofv3 databases are scratch (gpurun merges at most 64 MiB of gpurun_out/ back): keep the summaries
+[ "${KEEP_TRACE:-0}" = "1" ] || rm -rf $OUT/sq $OUT/lds $OUT/fetch $OUT/write $OUT/fetch_hk32 $OUT/write_hk32 $OUT/lds_hk32 $OUT/kt $OUT/kt_hk32
