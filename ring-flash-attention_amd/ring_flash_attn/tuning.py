@@ -90,8 +90,9 @@ def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
     inst = (_group_instance(group), key)
     if inst in _AGREED:
         return _TUNED.get(key)
-    if utils._loopback() is not None or world < 2:
-        return _TUNED.get(key)
+    if utils._loopback() is not None or utils.single_rank(world):
+        return _TUNED.get(key)             # (nobody to agree with; a one-rank group forced onto the multi-step path — the
+                                           #  RCCL test on a one-GPU box — does run the reduction below)
     if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
         return None
     code = _CODES[_TUNED.get(key)]

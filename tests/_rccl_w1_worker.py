@@ -102,6 +102,25 @@ def main(port):
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3", llama3=True)
     config.set(llama3_gather_max_bytes=0)                    # one K/V head group per collective
     varlen_case(R.llama3_flash_attn_varlen_func, "llama3[unfused]", llama3=True)
+    config.set(llama3_gather_max_bytes=1 << 30)
+    # llama3 with a PACKED kv (round 5): one all-gather of the packed tensor, one reduce-scatter into the packed gradient
+    q = torch.randn(T, H, D, generator=g).to(BF)
+    kv = torch.randn(T, 2, Hk, D, generator=g).to(BF)
+    do = torch.randn(T, H, D, generator=g).to(BF)
+    ro, rl, _, _ = O._flash_attn_varlen_forward(q, kv[:, 0], kv[:, 1], cu, cu, maxlen, maxlen, 0.0, scale, True)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(kv[:, 0]), torch.empty_like(kv[:, 1])
+    O._flash_attn_varlen_backward(do, q, kv[:, 0], kv[:, 1], ro, rl, rdq, rdk, rdv, cu, cu, maxlen, maxlen, 0.0, scale, True)
+    qd, kvd = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+    cq, ck, mq, mk, sl = R.llama3_flash_attn_prepare_cu_seqlens(cu, causal=True, rank=0, world_size=1)
+    out, lse, _ = R.llama3_flash_attn_varlen_kvpacked_func(qd, kvd, cq.to(dev), ck.to(dev), mq, mk, heads_k_stride=1,
+                                                           local_k_slice=sl, causal=True, return_attn_probs=True)
+    out.backward(do.to(dev))
+    torch.cuda.synchronize()
+    check("llama3[packed kv].out", out, ro, 2e-2)
+    check("llama3[packed kv].lse", lse, rl, 1e-3)
+    for n, a, b in (("dq", qd.grad, rdq), ("dk", kvd.grad[:, 0], rdk), ("dv", kvd.grad[:, 1], rdv)):
+        check(f"llama3[packed kv].{n}", a, b, 1e-2, 2e-2)
+    print("ok llama3[packed kv]", flush=True)
     # zigzag_llama3 (all-gather + re-order to stream order + fp32 reduce-scatter)
     q = torch.randn(T, H, D, generator=g).to(BF)
     k = torch.randn(T, Hk, D, generator=g).to(BF)
