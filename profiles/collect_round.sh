@@ -1,0 +1,32 @@
+#!/bin/bash
+# Everything under profiles/<TAG>_* in one GPU-box command (about 11 minutes on one MI355X):
+#     bash profiles/collect_round.sh [TAG=r05]
+#   PMC passes + traffic file + kernel trace (collect_pmc.sh), the bench rows of the reference's tables, the compute-only
+#   virtual ring, the shape sweep, the llama3 short-launch regime, the power probes, the C-ABI self test, smoke(), and the
+#   whole GPU suite.  Outputs: gpurun_out/<TAG>/ — copy what is to be judged into profiles/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r05}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+python -c "import sys; sys.path.insert(0,'ring-flash-attention_amd'); from ring_flash_attn import _C; print('build id', _C.load().rfa_build_id().decode())" > $O/build_id.txt 2>&1
+bash profiles/collect_pmc.sh $TAG > $O/collect_pmc.log 2>&1
+cp $R/gpurun_out/prof/${TAG}_* $O/ 2>/dev/null
+B="python bench.py --no-cpu-baseline"
+timeout 300 python bench.py > $O/${TAG}_bench_n1_default_flags.json 2> $O/bench.err
+timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_n1_driver_command.json 2>> $O/bench.err
+timeout 200 $B --kv-heads 32 > $O/${TAG}_bench_n1_mha.json 2>> $O/bench.err
+timeout 200 $B --forward-only > $O/${TAG}_bench_n1_forward_only.json 2>> $O/bench.err
+for wl in ring stripe ring_varlen zigzag_varlen llama3; do timeout 200 $B --workload $wl > $O/${TAG}_bench_n1_$wl.json 2>> $O/bench.err; done
+{ for vw in 2 4 8; do timeout 200 $B --no-breakdown --virtual-world $vw; done; timeout 200 $B --no-breakdown --virtual-world 8 --exchange ring; } > $O/${TAG}_virtual_ring.txt 2>> $O/bench.err
+timeout 300 python tools/shape_sweep.py > $O/${TAG}_shape_sweep.md 2>/dev/null
+{ timeout 120 python tools/small_launch.py --rank 7 2>/dev/null | grep -v Gloo; timeout 120 python tools/small_launch.py --rank 3 2>/dev/null | grep -v Gloo; } > $O/${TAG}_small_launch_llama3.txt
+timeout 200 python tools/power_probe.py --seconds 3 > $O/${TAG}_power_probe.json 2>/dev/null
+[ -x build/tools/mfma_power_probe ] || hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o build/tools/mfma_power_probe -lpthread
+timeout 200 build/tools/mfma_power_probe 6 > $O/${TAG}_mfma_power_probe.txt 2>&1
+timeout 200 python tools/graph_step.py > $O/${TAG}_graph_step.md 2>/dev/null
+( timeout 300 ./tests/native/selftest ) > $O/${TAG}_native_selftest.txt 2>&1
+( timeout 300 python __graft_entry__.py smoke ) > $O/${TAG}_smoke.txt 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 ) > $O/${TAG}_pytest_gpu.log 2>&1
+tail -4 $O/${TAG}_pytest_gpu.log; cut -c1-200 $O/${TAG}_bench_n1_default_flags.json
