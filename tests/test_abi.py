@@ -344,6 +344,33 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert lib.rfa_bwd(C.byref(bad), None) == -8
 
 
+def test_forward_split_plan_is_a_function_of_the_arguments(built):
+    """rfa_fwd_workspace_bytes reports the split-KV plan of a forward call (no device needed): few rows against many key
+    tiles are split; round 5: a half-filled grid of 256-row workgroups with >= 128 key tiles takes two shares (of 256-row
+    workgroups: rfa_api.cpp fwd_split_256_rows); a named form never splits by itself, a forced share count always does"""
+    from ring_flash_attn import _C
+
+    lib = _C.load()
+
+    def plan(B, Sq, Sk, H, Hk, D=128, form=_C.FWD_AUTO, nsplit=0):
+        a = _C.FwdArgs()
+        a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype, a.causal = B, Sq, Sk, H, Hk, D, 0, 1
+        a.fwd_form, a.kv_nsplit = form, nsplit
+        n = C.c_int32()
+        nbytes = lib.rfa_fwd_workspace_bytes(C.byref(a), C.byref(n))
+        assert nbytes == (n.value * B * Sq * H * (D + 1) * 4 if n.value > 1 else 0)
+        return n.value
+
+    assert plan(1, 8192, 8192, 32, 8) == 1                       # the headline: 1024 workgroups
+    assert plan(1, 256, 4096, 4, 2) == 2                         # few rows, 64 tiles
+    assert plan(1, 2048, 16384, 16, 8) == 2 and plan(1, 2048, 8192, 16, 8) == 2      # llama3 head groups (round 5 rule)
+    assert plan(1, 2048, 4096, 16, 8) == 2                       # (64 tiles: the 128-row rule)
+    assert plan(1, 2048, 2048, 16, 8) == 1                       # short chains are not split
+    assert plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32) == 1 and plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32, nsplit=3) == 3
+    assert plan(1, 2048, 16384, 16, 8, nsplit=1) == 1
+    assert plan(1, 2048, 16384, 16, 8, D=96) == 1                # (head dims without the split forms)
+
+
 def test_bench_accounting_matches_the_survey():
     """bench.py's algorithmic FLOP and byte accounting (no GPU): SURVEY.md section 8(d) fixes the headline at
     3.5 * 2*B*H*D*8192^2 * W = 1.9242e12 * W FLOP per GPU and iteration (causal counted as half, bwd = 2.5 fwd)

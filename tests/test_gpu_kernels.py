@@ -921,6 +921,8 @@ def test_fwd_128_row_form_matches_oracle_and_the_256_row_form(monkeypatch, B, Sq
 
 @pytest.mark.parametrize("B,Sq,Sk,H,Hk,D,causal,nsplit", [
     (1, 256, 4096, 4, 2, 128, True, "0"),        # the regime it exists for: few rows, 64 key tiles -> 2 shares (the library's choice)
+    (1, 2048, 8192, 16, 8, 128, True, "0"),      # round 5: a half-filled grid of 256-row workgroups with 128 key tiles -> TWO SHARES OF
+                                                 # 256-ROW workgroups (rfa_api.cpp: fwd_split_256_rows; a llama3 head group at 2048 rows)
     (2, 200, 3000, 2, 2, 128, True, "3"),        # ragged tails, bottom-right alignment, odd tile count, forced 3 shares
     (1, 300, 1000, 2, 1, 64, False, "8"),        # head dim 64; more shares than tile pairs: empty shares
     (1, 700, 520, 2, 2, 128, True, "2"),         # more queries than keys: rows without any key (lse = +inf)
