@@ -273,10 +273,14 @@ __device__ __forceinline__ void dma_load128(dma_rsrc_t r, int lds_wave_base, int
                : "v"(voffset), "s"(r.w), "s"(__builtin_amdgcn_readfirstlane(lds_wave_base))
                : "m0");
 }
-// s_waitcnt vmcnt(n), n < 16, lgkmcnt / expcnt untouched
+// s_waitcnt vmcnt(n), n < 64, lgkmcnt / expcnt untouched (gfx9 encoding: vmcnt = simm16[3:0] | simm16[15:14] << 4).
+// Round 5: until now only the low four bits were encoded — correct for every n < 16, but the 128-row form of dq_ds_kernel
+// asks for 16 (two tiles of 8 DMA instructions may stay in flight), which encoded as vmcnt(0): that form drained its whole
+// ring at every tile and ran latency-bound (a llama3 head group: 1.07 GB of dS at 3.9 TB/s instead of the stream's 5.5+).
 template <int n>
 __device__ __forceinline__ void wait_vmem() {
-  __builtin_amdgcn_s_waitcnt(0x0F70 | n);
+  static_assert(n >= 0 && n < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (n & 15) | ((n >> 4) << 14));
 }
 // 4-byte buffer load hidden from the compiler's waitcnt bookkeeping (like the LDS DMA above): the caller
 // counts it in its own wait_vmem<n>() and must then pass the result through load_landed() before using it.

@@ -36,6 +36,9 @@
 #ifndef RFA_DQS_NT
 #define RFA_DQS_NT 1         // 1: the dS stream is fetched with the non-temporal policy (0.41 -> 0.35 ms)
 #endif
+#ifndef RFA_DQS_STAGES4
+#define RFA_DQS_STAGES4 4    // ring depth of the 4-wave (128-row) form: 4 = three tiles in flight (128 KiB), 5 = four (160 KiB)
+#endif
 
 namespace rfa {
 
@@ -49,7 +52,7 @@ constexpr int kDsWaveBytes = 2 * kDsBlockBytes;        // 4 KiB of dS per wave a
 template <int kW> struct DsGeo {
   static constexpr int kThreads = kW * 64;
   static constexpr int kRows = kW * 32;                // query rows per workgroup
-  static constexpr int kStages = kW == 8 ? 3 : 4;
+  static constexpr int kStages = kW == 8 ? 3 : RFA_DQS_STAGES4;
   static constexpr int kSBytes = kW * kDsWaveBytes;    // 32 / 16 KiB of dS per tile
   static constexpr int kSmem = kStages * (kDsKBytes + kSBytes);
   static constexpr int kKPieces = 16 / kW;             // 1 KiB K pieces per wave and tile
@@ -183,14 +186,17 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   typedef std::integral_constant<int, 1> st1;
   typedef std::integral_constant<int, 2> st2;
   typedef std::integral_constant<int, 3> st3;
+  typedef std::integral_constant<int, 4> st4;
   constexpr int kFly = (kDsStages - 2) * Geo::kDmaPerTile;   // DMA instructions that may stay in flight behind the tile awaited
   load_tile(0, st0{});
   if (ntiles >= kDsStages - 1) {
     load_tile(1, st1{});
     if (kDsStages > 3) load_tile(2, st2{});
+    if (kDsStages > 4) load_tile(3, st3{});
     wait_vmem<kFly>();
   } else {
     if (ntiles > 1) load_tile(1, st1{});
+    if (kDsStages > 4 && ntiles > 2) load_tile(2, st2{});
     wait_all_vmem();
   }
   __syncthreads();
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
     if (j + 1 < ntiles) tile_step(j + 1, st1{});
     if (j + 2 < ntiles) tile_step(j + 2, st2{});
     if (kDsStages > 3 && j + 3 < ntiles) tile_step(j + 3, st3{});
+    if (kDsStages > 4 && j + 4 < ntiles) tile_step(j + 4, st4{});
   }
 
   if (qrow >= lq) return;
