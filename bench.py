@@ -854,11 +854,15 @@ def main():
             for _ in range(2):
                 step()
             counter[0] = 0
+            torch.cuda.reset_peak_memory_stats(dev)
             vms = timed(args.steps) / args.steps * 1e3
+            vpeak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
         finally:
             rfa_testing.set_loopback(None)
         result["virtual_ring"] = {
             "world": vw, "rank": vr, "ms_per_step": vms, "ideal_ms": vw * ms, "efficiency": vw * ms / vms,
+            # allocator peak of one rank's steps at this world size in this exchange form (gather: O(S_total) scratch)
+            "peak_device_memory_gib": round(vpeak, 3),
             "exchange": exchange_mode(kv.detach()[:, :, 0], vw) if wl == "zigzag" else None,
             "note": "one rank's exact kernel sequence at this world size, exchange looped back to local buffers; "
                     "ideal = world x the measured world-size-1 step",
