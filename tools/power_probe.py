@@ -108,6 +108,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--phases", default="idle,fwd,dkdv,dq,bwd,step,step_7gemm,copy")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "ternary"],
+                    help="operand data (diagnostic: the chip's power, and with it the rate it sustains, depends on how many "
+                         "bits toggle): randn = the benchmark's N(0,1); zeros; ternary = values from {-1, 0, 1}")
     args = ap.parse_args()
     import torch
 
@@ -117,10 +120,14 @@ def main():
     be, dev = get_backend(), torch.device("cuda:0")
     S, H, Hk, D = 8192, 32, 8, 128
     torch.manual_seed(0)
-    q = torch.randn(1, S, H, D, device=dev, dtype=torch.bfloat16)
-    k = torch.randn(1, S, Hk, D, device=dev, dtype=torch.bfloat16)
-    v = torch.randn(1, S, Hk, D, device=dev, dtype=torch.bfloat16)
-    do = torch.randn_like(q)
+    def mk(*shape):
+        if args.data == "zeros":
+            return torch.zeros(*shape, device=dev, dtype=torch.bfloat16)
+        if args.data == "ternary":
+            return torch.randint(-1, 2, shape, device=dev).to(torch.bfloat16)
+        return torch.randn(*shape, device=dev, dtype=torch.bfloat16)
+
+    q, k, v, do = mk(1, S, H, D), mk(1, S, Hk, D), mk(1, S, Hk, D), mk(1, S, H, D)
     out, lse = torch.empty_like(q), torch.empty(1, H, S, device=dev, dtype=torch.float32)
     delta = torch.empty_like(lse)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -156,7 +163,8 @@ def main():
     }
     smp = Sampler()
     smp.start()
-    res = {"power_source": smp.pfiles or "amd-smi / rocm-smi", "freq_source": smp.ffiles, "device": torch.cuda.get_device_name(dev)}
+    res = {"power_source": smp.pfiles or "amd-smi / rocm-smi", "freq_source": smp.ffiles, "device": torch.cuda.get_device_name(dev),
+           "data": args.data}
     for name in args.phases.split(","):
         fn, flops = phases[name]
         if name == "step_7gemm":
