@@ -46,7 +46,7 @@ def run(B, S, H, Hk, D, causal, dtype=torch.bfloat16):
 
     tb = timeit(bwd, n)
     fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
-    print(f"| {B} | {S} | {H}/{Hk} | {D} | {'causal' if causal else 'full'} | {tf:.3f} | {fl / tf / 1e9:.0f} | {tb:.3f} | "
+    print(f"| {B} | {S} | {H}/{Hk} | {D} | {'causal' if causal else 'full'}{'' if dtype == torch.bfloat16 else ' fp16'} | {tf:.3f} | {fl / tf / 1e9:.0f} | {tb:.3f} | "
           f"{2.5 * fl / tb / 1e9:.0f} |", flush=True)
 
 
