@@ -398,34 +398,6 @@ static DsChunks bwd_ds_chunking(const rfa_bwd_args* a) {
   return DsChunks{a->Hk * (G / gc), 1, gc, per * gc};
 }
 
-// dQ from dS (rfa_dqs.hip) is bound by the LDS-DMA rate of a CU, and K tiles are a third (256-row workgroups) or half
-// (128-row ones) of what it stages.  A grid with about HALF a 256-row workgroup per CU — a llama3 head group at 2048 rows
-// against the gathered keys of 8 ranks — used to take the 128-row form to fill the chip; round 5 instead shares the key tiles
-// of every 256-row workgroup between TWO workgroups (fp32 partials in the workspace, summed by reduce_kernel: 2 x rows x H x D
-// x 4 bytes, 33 MB there against 1.07 GB of dS).  Single-phase calls whose hand-off is one launch pair, head dim 128.
-static int bwd_dq_nsplit(const rfa_bwd_args* a) {
-  if (a->D != kHeadDim || !bwd_single_phase(a) || (a->phases & (RFA_BWD_SKIP_DQ | RFA_BWD_SKIP_DKDV))) return 1;
-  if (bwd_ds_chunking(a).nchunks != 1) return 1;
-  // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) row blocks per head, of which only
-  // about total_q / 256 (+ one tail per sequence) are not past the end of their sequence
-  int64_t qblocks = (int64_t)a->B * ((eff_len(a->Sq, a->q_half) + 255) / 256);
-  if (a->cu_seqlens_q != nullptr && a->total_q > 0) {
-    const int64_t eff = (a->total_q + 255) / 256 + a->B;
-    qblocks = eff < qblocks ? eff : qblocks;
-  }
-  const int64_t wgs8 = qblocks * a->H;
-  const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
-  return (wgs8 >= 112 && wgs8 <= 192 && tiles >= 128) ? 2 : 1;
-}
-static int64_t bwd_q_rows_total(const rfa_bwd_args* a) {
-  if (a->cu_seqlens_q != nullptr) return a->total_q > 0 ? a->total_q : a->total_k;
-  return (int64_t)a->B * a->Sq;
-}
-static int64_t bwd_dq_part_bytes(const rfa_bwd_args* a) {
-  const int ns = bwd_dq_nsplit(a);
-  return ns > 1 ? (int64_t)ns * bwd_q_rows_total(a) * a->H * a->D * 4 : 0;
-}
-
 int rfa_bwd_ds_chunks(const rfa_bwd_args* a, int32_t* nchunks, int32_t* kv_heads, int32_t* q_heads, int64_t* chunk_bytes) {
   if (!a) return RFA_ERR_NULL;
   if (int rc = check_common(a->dtype, a->H, a->Hk, a->D, a->B)) return rc;
@@ -446,17 +418,12 @@ int rfa_bwd_plan(const rfa_bwd_args* a, int32_t* form, int32_t* nsplit, int32_t*
   return RFA_OK;
 }
 
-static int64_t bwd_kv_part_bytes(const rfa_bwd_args* a) {
-  if (!bwd_needs_ws(a)) return 0;
+int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
+  if (!a || !bwd_needs_ws(a)) return 0;
   // unsplit: one io-dtype partial per element; split launches: nsplit fp32 partials
   const int ns = bwd_dkdv_plan(a).nsplit;
   const bool f32 = ns > 1 || bwd_ds_chunking(a).gc < a->H / a->Hk;
   return 2 * a->total_k * (int64_t)a->Hk * a->D * (f32 ? 4 * ns : 2);
-}
-int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
-  if (!a) return 0;
-  // dK / dV partials, then (16-byte aligned: both are multiples of D * 2 bytes) the fp32 dQ partials of a split dQ launch
-  return bwd_kv_part_bytes(a) + bwd_dq_part_bytes(a);
 }
 
 int rfa_bwd(const rfa_bwd_args* a, void* stream) {
@@ -473,8 +440,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   if (a->dkdv_form < RFA_DKDV_AUTO || a->dkdv_form > RFA_DKDV_256 || a->dkdv_nsplit < 0) return RFA_ERR_ARGS;
   if (!drop_args_ok(a->dropout_p, a->window, a->window_left, a->window_right, a->causal)) return RFA_ERR_ARGS;
   const bool ws = bwd_needs_ws(a);
-  const int dq_ns = bwd_dq_nsplit(a);
-  if ((ws || dq_ns > 1) && !a->workspace) return RFA_ERR_NULL;
+  if (ws && !a->workspace) return RFA_ERR_NULL;
   if (!aligned16(a->dout) || !aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v))
     return RFA_ERR_ALIGN;
   if (!stride_ok(a->dout_st, 2) || !stride_ok(a->q_st, 2) || !stride_ok(a->k_st, 2) || !stride_ok(a->v_st, 2))
@@ -584,28 +550,8 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
         if (!(a->phases & RFA_BWD_SKIP_DKDV))
           if (int rc2 = launch_bwd_dkdv(pc, a->dtype, st)) return launch_status(rc2);
         if (c == 0) mark(1);
-        if (!(a->phases & RFA_BWD_SKIP_DQ)) {
-          if (dq_ns > 1) {                 // (one chunk, single-phase: bwd_dq_nsplit)
-            pc.dq_nsplit = dq_ns;
-            pc.dq_part = (float*)((char*)a->workspace + bwd_kv_part_bytes(a));
-            pc.dq_part_split = bwd_q_rows_total(a) * a->H * a->D;
-          }
+        if (!(a->phases & RFA_BWD_SKIP_DQ))
           if (int rc2 = launch_bwd_dq_from_ds(pc, a->dtype, st)) return launch_status(rc2);
-          if (dq_ns > 1) {
-            // dq (io dtype) = / dq_acc (+)= the sum of the shares' fp32 partials, rounded once
-            ReduceParams r{};
-            r.src = pc.dq_part;
-            r.src_st = Strides{a->cu_seqlens_q ? 0 : (int64_t)a->Sq * a->H * a->D, (int64_t)a->H * a->D, (int64_t)a->D};
-            r.src_f32 = 1;
-            r.g_stride = pc.dq_part_split;
-            r.cu_k = a->cu_seqlens_q;
-            r.B = a->B; r.Hk = a->H; r.G = dq_ns; r.D = a->D; r.Sk = a->Sq; r.k_half = a->q_half;
-            r.acc_init = a->acc_init ? 1 : 0;
-            if (a->dq_acc) { r.dst_acc = a->dq_acc; r.dst_acc_st = cv(a->dq_acc_st); }
-            else { r.dst = a->dq; r.dst_st = cv(a->dq_st); }
-            if (launch_reduce(r, a->dtype, st)) return RFA_ERR_LAUNCH;
-          }
-        }
       }
       mark(2);
     } else {

@@ -89,9 +89,6 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   const int G = p.H / p.Hk;
   const int hk = idx % p.Hk;
   idx /= p.Hk;
-  const int nsp = p.dq_nsplit > 1 ? p.dq_nsplit : 1;     // shares of this workgroup's key tiles (1: the whole range)
-  const int split = idx % nsp;
-  idx /= nsp;
   const int gq = idx % G;
   idx /= G;
   const int qblk = p.nqblk - 1 - (idx % p.nqblk);
@@ -128,10 +125,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   const int qend = (qwg0 + kDsRows < lq) ? qwg0 + kDsRows : lq;
   int kmax = lk;                                        // (windowed calls are not eligible for the spill path)
   if (p.causal && qend + off < kmax) kmax = qend + off;
-  const int ntiles_all = kmax > 0 ? (kmax + kDsKV - 1) / kDsKV : 0;
-  // split launch: this workgroup walks tiles jt0 .. jt0 + ntiles - 1 of the range (contiguous shares)
-  const int jt0 = (int)((int64_t)ntiles_all * split / nsp);
-  const int ntiles = (int)((int64_t)ntiles_all * (split + 1) / nsp) - jt0;
+  const int ntiles = kmax > 0 ? (kmax + kDsKV - 1) / kDsKV : 0;
 
   // K tile DMA: as in the forward kernel (lane L of the piece for row group c = wave + 8 i lands in row
   // 4c + L/16, physical chunk L%16 and fetches the logical chunk the swizzle puts there)
@@ -145,9 +139,8 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
     voff_k[i] = chunk * 8 < p.D ? (row * (int)p.k_st.row + chunk * 8) * 2 : 0x7ffffff0;
   }
   const int voff_s = lane * 16;
-  auto load_tile = [&](int jrel, auto stage) {
+  auto load_tile = [&](int j, auto stage) {
     constexpr int kStage = decltype(stage)::value;
-    const int j = jt0 + jrel;
     int rows = lk - j * kDsKV;
     rows = rows < kDsKV ? rows : kDsKV;
     const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
@@ -218,7 +211,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
     if (qw0 < lq) {
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        const int kw0 = (jt0 + j) * kDsKV + 32 * blk;
+        const int kw0 = j * kDsKV + 32 * blk;
         // exactly the predicate under which dkdv_kernel wrote this block
         const bool active = (kw0 < lk) && !(p.causal && qw0 + 31 + off < kw0);
         if (active) {
@@ -253,17 +246,12 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   }
 
   if (qrow >= lq) return;
-  if (p.dq_acc == nullptr && nsp == 1) {
+  if (p.dq_acc == nullptr) {
     T* ob = (T*)p.dq + qbatch * p.dq_st.batch + (qs.row0 + qrow) * p.dq_st.row + (int64_t)h * p.dq_st.head;
     store_rows16<T, false>(ob, dq, p.scale, g, p.D, true);
   } else {
-    // fp32 accumulators of the call — or, split launch, this share's fp32 partial (overwritten: every share stores
-    // every row of its workgroup, a share without tiles stores zeros)
-    float* ab = nsp > 1 ? p.dq_part + (int64_t)split * p.dq_part_split +
-                              ((qbatch * p.Sq + qs.row0 + qrow) * p.H + h) * (int64_t)p.D
-                        : p.dq_acc + qbatch * p.dq_acc_st.batch + (qs.row0 + qrow) * p.dq_acc_st.row +
-                              (int64_t)h * p.dq_acc_st.head;
-    const bool overwrite = nsp > 1 || p.acc_init;
+    float* ab = p.dq_acc + qbatch * p.dq_acc_st.batch + (qs.row0 + qrow) * p.dq_acc_st.row +
+                (int64_t)h * p.dq_acc_st.head;
 #pragma unroll
     for (int dblk = 0; dblk < 4; ++dblk)
 #pragma unroll
@@ -271,7 +259,7 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
         const int d0 = 32 * dblk + 8 * jj + 4 * g;
         if (d0 >= p.D) continue;
         f32x4 x;
-        if (overwrite) {
+        if (p.acc_init) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = 0.f;
         } else {
@@ -291,7 +279,7 @@ static int launch_dq_ds_w(BwdParams p, hipStream_t stream) {
   if (int rc = opt_in_dynamic_lds((const void*)dq_ds_kernel<T, kW>, Geo::kSmem, attr_done)) return rc;
   const int lq = p.q_half ? (p.Sq + 1) / 2 : p.Sq;       // (the longest (half) sequence: rfa_api.cpp eff_len)
   p.nqblk = (lq + Geo::kRows - 1) / Geo::kRows;
-  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B * (p.dq_nsplit > 1 ? p.dq_nsplit : 1);
+  const int64_t nblocks = (int64_t)p.nqblk * p.H * p.B;
   if (nblocks <= 0) return 0;
   hipLaunchKernelGGL((dq_ds_kernel<T, kW>), dim3((unsigned)nblocks), dim3(Geo::kThreads), Geo::kSmem, stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
@@ -305,8 +293,7 @@ static int launch_dq_ds_t(const BwdParams& p, hipStream_t stream) {
 #ifndef RFA_DQS_FORM
 #define RFA_DQS_FORM 0       // tuning: 8 / 4 = always that form
 #endif
-  // (a split launch — rfa_api.cpp: bwd_dq_nsplit — shares the key tiles of 256-row workgroups: K is staged once per 256 rows)
-  const bool small = RFA_DQS_FORM == 4 || (RFA_DQS_FORM == 0 && wgs8 < 256 && p.dq_nsplit <= 1);
+  const bool small = RFA_DQS_FORM == 4 || (RFA_DQS_FORM == 0 && wgs8 < 256);
   return small ? launch_dq_ds_w<T, 4>(p, stream) : launch_dq_ds_w<T, 8>(p, stream);
 }
 

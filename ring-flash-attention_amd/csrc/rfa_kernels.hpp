@@ -99,11 +99,6 @@ struct BwdParams {
   int64_t kv_split_stride;
   int kv_part_f32;     // dk / dv point to fp32 PARTIALS in the workspace (split launches): fp32 stores, strides in fp32 elements
   int kv_accum;        // fp32 stores ADD to what the partial holds (later query-head fractions of a chunked dS hand-off)
-  // dQ from dS with the key range of every workgroup shared by dq_nsplit workgroups (rfa_dqs.hip, round 5): share s stores
-  // its fp32 partial at dq_part + s * dq_part_split, laid out (rows, H, D) contiguous; reduce_kernel sums them into dq / dq_acc
-  int dq_nsplit;
-  float* dq_part;
-  int64_t dq_part_split;
   // dropout (rfa_common.hpp: drop_word): keep threshold 0..256 (256 = off), scale of kept probabilities, seed and
   // the offsets that turn local (head, query position, key position) into global ones
   unsigned drop_keep;

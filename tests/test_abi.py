@@ -222,7 +222,7 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     lib = _C.load()
 
     def args(B, Sq, Sk, H, Hk, D=128, varlen_total=None, acc=False, phases=0, window=None, halves=(0, 0),
-             causal=False, form=0, nsplit=0, scratch=False):
+             causal=False, form=0, nsplit=0):
         a = _C.BwdArgs()
         a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype = B, Sq, Sk, H, Hk, D, 0
         a.total_k = varlen_total if varlen_total is not None else B * Sk
@@ -236,9 +236,6 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
         a.dkdv_form, a.dkdv_nsplit = form, nsplit
         if window:
             a.window, a.window_left, a.window_right = 1, window[0], window[1]
-        if scratch:                                             # the caller hands over the whole dS hand-off (5-GEMM form)
-            a.total_q = B * Sq
-            a.ds_scratch, a.ds_scratch_bytes = 16, lib.rfa_bwd_ds_scratch_bytes(C.byref(a))
         return a
 
     unit = lambda rows, Hk, D=128: 2 * rows * Hk * D * 2        # one (dK, dV) partial set in the io dtype
@@ -286,13 +283,6 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit32(8192, 8)
     assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True)) == 32 * (256 + 3) * 231 * 2048
     assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 32 * (256 + 3) * 116 * 2048
-    # round 5: dQ from dS on a half-filled grid of 256-row workgroups with >= 128 key tiles (a llama3 head group) shares every
-    # workgroup's key tiles between two workgroups: 2 x rows x H x D fp32 partials behind the dK / dV partials
-    assert ws(args(1, 2048, 16384, 16, 8, causal=True, scratch=True)) == 2 * 2048 * 16 * 128 * 4
-    assert ws(args(1, 2048, 16384, 16, 8, causal=True)) == 0                        # (no scratch: the 7-GEMM form has no such launch)
-    assert ws(args(1, 2048, 4096, 16, 8, causal=True, scratch=True)) == 0           # (64 key tiles: not split)
-    assert ws(args(1, 2048, 16384, 16, 8, causal=True, scratch=True, phases=_C.BWD_COMPUTE)) == unit(16384, 8)   # (two-phase calls neither)
-    assert ws(args(1, 8192, 8192, 32, 8, causal=True, scratch=True)) == 2 * unit32(8192, 8)         # (the headline: full grid)
     # the overrides are arguments ...
     assert ws(args(1, 8192, 8192, 32, 8, form=_C.DKDV_128)) == 0
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == (_C.DKDV_256, 3)

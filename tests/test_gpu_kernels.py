@@ -509,61 +509,6 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
 
 
 @pytest.mark.extended
-@pytest.mark.parametrize("packed", [False, True])
-def test_dq_from_ds_with_shared_key_tiles(monkeypatch, packed):
-    """Round 5: dQ from dS on a half-filled grid of 256-row workgroups with >= 128 key tiles — a llama3 head group: 2048 local
-    queries against 8192 gathered keys, 16 / 8 heads — shares every workgroup's key tiles between two workgroups (fp32
-    partials in the workspace, reduce_kernel; rfa_api.cpp: bwd_dq_nsplit).  Dense and packed (two sequences), plain io
-    output and fp32 accumulate (+=), against the CPU oracle and against the 7-GEMM form (which has no such launch)."""
-    import ctypes as C
-
-    from ring_flash_attn import _C
-    from ring_flash_attn.backend import get_backend
-    from ring_flash_attn._testing import set_backend
-
-    set_backend(None)
-    be, dev = get_backend(), _dev()
-    g = torch.Generator().manual_seed(31)
-    H, Hk, D = 16, 8, 128
-    if packed:
-        cu_q = torch.tensor([0, 700, 2048], dtype=torch.int32)
-        cu_k = torch.tensor([0, 2700, 8192], dtype=torch.int32)
-        q, do = (torch.randn(2048, H, D, generator=g).to(BF) for _ in range(2))
-        k, v = (torch.randn(8192, Hk, D, generator=g).to(BF) for _ in range(2))
-        ro, rl, rdq, rdk, rdv = _oracle_varlen(q, k, v, do, cu_q, cu_k, True)
-        kw = dict(softmax_scale=D ** -0.5, causal=True, cu_seqlens_q=cu_q.to(dev), cu_seqlens_k=cu_k.to(dev),
-                  max_seqlen_q=2048, max_seqlen_k=8192)
-        lse = torch.empty((H, 2048), dtype=torch.float32, device=dev)
-        pre = dict(cu_seqlens_q=kw["cu_seqlens_q"], max_seqlen_q=2048)
-    else:
-        q, do = (torch.randn(1, 2048, H, D, generator=g).to(BF) for _ in range(2))
-        k, v = (torch.randn(1, 8192, Hk, D, generator=g).to(BF) for _ in range(2))
-        ro, rl, rdq, rdk, rdv = _oracle_dense(q, k, v, do, True)
-        kw = dict(softmax_scale=D ** -0.5, causal=True)
-        lse = torch.empty((1, H, 2048), dtype=torch.float32, device=dev)
-        pre = {}
-    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
-    out = torch.empty_like(qd)
-    be.fwd(qd, kd, vd, out=out, lse=lse, **kw)
-    delta = torch.empty_like(lse)
-    be.bwd_preprocess(dod, out, delta, **pre)
-    res = {}
-    for spill in ("1", "0"):
-        monkeypatch.setenv("RFA_BWD_DS_SPILL", spill)
-        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-        be.bwd(dod, qd, kd, vd, lse, delta, dq=dq, dk=dk, dv=dv, **kw)
-        _grads_ok(f"dq split packed={packed} spill={spill}", (dq, dk, dv), (rdq, rdk, rdv))
-        dqa = torch.full(qd.shape, 3.0, dtype=torch.float32, device=dev)
-        dka = torch.zeros(kd.shape, dtype=torch.float32, device=dev)
-        dva = torch.zeros_like(dka)
-        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, **kw)          # += into fp32
-        _check(f"dq split packed={packed} spill={spill} acc", dqa - 3.0, rdq.float(), 0, kind="grad")
-        res[spill] = (dq, dk, dv)
-    _check("dq: shared key tiles vs the 7-GEMM form", res["1"][0], res["0"][0].float(), 0, kind="grad")
-    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][2], res["0"][2])
-
-
-@pytest.mark.extended
 @pytest.mark.parametrize("causal", [True, False])
 def test_ds_spill_packed_sequences_with_longer_keys(monkeypatch, causal):
     """dS-spill backward on packed sequences whose K/V are longer than Q (the llama3 shape: local queries against
