@@ -74,36 +74,37 @@ def test_kept_kv_is_owned_by_the_autograd_graph():
     assert ret[0] == want and ret[1] == want, dict(ret)
 
 
-@pytest.mark.timeout(300)
-def test_collective_sequence_survives_rank_local_state():
+@pytest.mark.timeout(400)
+@pytest.mark.parametrize("W", [2, 4])
+def test_collective_sequence_survives_rank_local_state(W):
     """the keep / re-gather choice of the zigzag gather form reads a process-local byte budget, the
     exchange form a process-local tuning record — ranks whose local state disagrees must still post the SAME collectives.
-    Two gloo ranks; one rank's budget exhausted (by configuration, and by a graph only it keeps alive), a tuning record
-    on one rank only, different records, the same record: every call finishes, the posted collectives are identical on
-    both ranks, and the gradients are those of the symmetric run (bit for bit)."""
+    W gloo ranks; one rank's budget exhausted (by configuration — every rank in turn —, and by a graph only rank 0 keeps
+    alive), a tuning record on one rank only, different records, the same record: every call finishes, the posted
+    collectives are identical on all ranks, and the gradients are those of the symmetric run (bit for bit)."""
     import torch.multiprocessing as mp
     import _consistency_worker as CW
 
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(CW.run, args=(2, free_port(), ret), nprocs=2, join=True)
-    a, b = ret[0], ret[1]
+    mp.spawn(CW.run, args=(W, free_port(), ret), nprocs=W, join=True)
+    res = [ret[r] for r in range(W)]
     kept_path = ["all_gather", "all_to_all"]                        # forward gathers; the backward only returns dK/dV
     regather_path = ["all_gather", "all_gather", "all_to_all"]      # ... and gathers K/V a second time
-    for r in (a, b):
+    for r in res:
         assert r["both_keep"] == (kept_path, 6) and r["none_keep"] == (regather_path, 5), r
         assert r["close_keep_vs_not"]
-        for name in ("budget_rank0", "budget_rank1", "held_graph"):
+        for name in [f"budget_rank{x}" for x in range(W)] + ["held_graph"]:
             assert r[name]["posted"] == regather_path and r[name]["same_as_no_keep"], (name, r[name])
         for name in ("record_rank0_only", "records_differ"):
             assert r[name]["posted"] == kept_path and r[name]["same_as_keep"], (name, r[name])
             assert r[name]["mine_after"] in (None, "-")
         assert set(r["record_everywhere"]["posted"]) == {"hop"}, r["record_everywhere"]
-    # the rank that could keep did save its buffers (6 saved tensors), the other not (5): the DECISION was the group's
-    assert (a["budget_rank0"]["n_saved"], b["budget_rank0"]["n_saved"]) == (5, 6)
-    assert (a["budget_rank1"]["n_saved"], b["budget_rank1"]["n_saved"]) == (6, 5)
-    assert (a["held_graph"]["n_saved"], b["held_graph"]["n_saved"]) == (5, 6)
-    assert a["record_rank0_only"]["mine_after"] is None
+    # the ranks that could keep did save their buffers (6 saved tensors), the loser not (5): the DECISION was the group's
+    for loser in range(W):
+        assert [res[r][f"budget_rank{loser}"]["n_saved"] for r in range(W)] == [5 if r == loser else 6 for r in range(W)]
+    assert [res[r]["held_graph"]["n_saved"] for r in range(W)] == [5] + [6] * (W - 1)
+    assert res[0]["record_rank0_only"]["mine_after"] is None
 
 
 def test_bench_launches_its_own_ranks():
