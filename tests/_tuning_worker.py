@@ -40,7 +40,25 @@ def run(rank, W, port, ret, break_gather):
     with config.override(zigzag_exchange="ring"):
         forced = Z.exchange_mode(k, W, q)
     probe = None if break_gather else tuning.comm_probe(None, torch.device("cpu"), 1 << 16, iters=2, warm=1)
+    # the in-call path (config.autotune, opt-in): same measurement, never raises — with EVERY form broken (on all ranks
+    # alike) it returns None, leaves the shape rule in charge and does not try again
+    tuning.clear()
+    in_call = tuning.measure_in_call(None, q, k, v)
+    in_call_none = None
+    if break_gather:
+        def broken_hop(self, *a, **kw):
+            raise RuntimeError("simulated isend failure")
+
+        tuning.clear()
+        saved = Z.RingComm.send_recv_kv
+        Z.RingComm.send_recv_kv = broken_hop
+        try:
+            in_call_none = [tuning.measure_in_call(None, q, k, v), tuning.measure_in_call(None, q, k, v),
+                            Z.exchange_mode(k, W, q)]
+        finally:
+            Z.RingComm.send_recv_kv = saved
     ret[rank] = dict(before=before, chosen=rep["chosen"], after=after, forced=forced, ms=rep["ms"], failed=rep["failed"],
-                     probe=probe, other_shape=Z.exchange_mode(k[:, :32], W, q[:, :32]))
+                     probe=probe, other_shape=Z.exchange_mode(k[:, :32], W, q[:, :32]), in_call=in_call,
+                     in_call_none=in_call_none)
     dist.barrier()
     dist.destroy_process_group()

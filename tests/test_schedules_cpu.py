@@ -183,7 +183,9 @@ def test_exchange_autotune_is_a_collective_decision(break_gather):
     assert a["chosen"] == b["chosen"] == a["after"] == b["after"]
     assert a["forced"] == b["forced"] == "ring" and a["other_shape"] == "gather"
     assert a["ms"] == b["ms"]                                     # max over ranks: identical on both
+    assert a["in_call"] == b["in_call"] == a["chosen"]               # the opt-in in-call measurement: same decision
     if break_gather:
+        assert a["in_call_none"] == b["in_call_none"] == [None, None, "gather"]      # every form broken: no raise, the shape rule
         assert a["chosen"] == "ring" and a["ms"]["gather"] is None and "gather" in a["failed"] and "gather" in b["failed"]
     else:
         assert all(v_ is not None and v_ > 0 for v_ in a["ms"].values())
