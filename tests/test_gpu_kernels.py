@@ -509,6 +509,49 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
 
 
 @pytest.mark.extended
+def test_ds_scratch_capped_by_free_memory_is_kept(monkeypatch):
+    """ADVICE r4: a dS scratch that the free-memory fraction CAPPED when it was taken is smaller than the hand-off for ever;
+    it must be reused as it is (the hand-off then runs in head-group chunks over it) instead of being dropped, re-queried
+    and re-made in every backward.  The allocator queries are replaced by fixed answers so that the cap is deterministic:
+    34 MB of dS (8 heads, S = 2048, causal), 20 MB granted."""
+    from ring_flash_attn import backend as BK
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
+
+    set_backend(None)
+    be, dev = get_backend(), _dev()
+    be.release_scratch()
+    g = torch.Generator().manual_seed(41)
+    B, S, H, Hk, D = 1, 2048, 8, 2, 128
+    q, do = (torch.randn(B, S, H, D, generator=g).to(BF) for _ in range(2))
+    k, v = (torch.randn(B, S, Hk, D, generator=g).to(BF) for _ in range(2))
+    ro, rl, rdq, rdk, rdv = _oracle_dense(q, k, v, do, True)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out, lse = torch.empty_like(qd), torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=D ** -0.5, causal=True, out=out, lse=lse)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    queries = []
+    monkeypatch.setattr(BK, "_SPILL_CHECK_ABOVE", 0)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a: (queries.append(1), (40 << 20, 288 << 30))[1])
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a: 0)
+    bufs = []
+    for it in range(4):
+        dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        be.bwd(dod, qd, kd, vd, lse, delta, softmax_scale=D ** -0.5, causal=True, dq=dq, dk=dk, dv=dv)
+        _grads_ok(f"capped scratch, backward {it}", (dq, dk, dv), (rdq, rdk, rdv))
+        (buf,) = be._ds_pool.values()
+        bufs.append(buf)
+    assert all(b_ is bufs[0] for b_ in bufs) and bufs[0].numel() == 20 << 20      # one buffer, 0.5 x the 40 MB "free"
+    assert len(queries) == 1                                                        # the allocator was asked once, not per backward
+    (left,) = be._ds_capped.values()
+    assert left[0] == BK._SPILL_GROW_RETRY - 3
+    be.release_scratch()
+    assert not be._ds_pool and not be._ds_capped
+
+
+@pytest.mark.extended
 @pytest.mark.parametrize("causal", [True, False])
 def test_ds_spill_packed_sequences_with_longer_keys(monkeypatch, causal):
     """dS-spill backward on packed sequences whose K/V are longer than Q (the llama3 shape: local queries against
