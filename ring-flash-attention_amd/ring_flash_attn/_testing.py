@@ -61,4 +61,5 @@ def allow_host_staging(flag=True):
 def reset():
     """production state: no hooks, the HIP backend"""
     _utils._TEST = None
+    _utils._BACKEND_OF.clear()
     set_backend(None)

@@ -298,6 +298,11 @@ class HipBackend:
             if cap < want:
                 want = cap
                 capped = True
+        if buf is not None and buf.numel() >= least and want <= buf.numel():
+            # a growth retry that would not GROW the pooled buffer (memory is as tight as before, or tighter): keep what
+            # works — never trade a usable scratch for a smaller one or for the 7-GEMM form — and try again later
+            self._ds_capped[key] = [_SPILL_GROW_RETRY]
+            return buf
         if want < least:
             _log_once("spill-mem", f"ring_flash_attn: not enough free memory for a dS hand-off chunk ({least / 2**30:.2f} GiB): "
                                    "this backward runs the 7-GEMM form")

@@ -203,9 +203,15 @@ class _KeptBudget:
 
         __del__ = release
 
+    def may_keep(self, nbytes) -> bool:
+        """the part of the decision that depends on the configuration and the call's size only — the same on every rank
+        of a group (nothing to agree on when it refuses); the live-bytes budget below is the rank-local part"""
+        c = get()
+        return bool(c.kv_keep) and nbytes <= c.kv_keep_bytes
+
     def try_reserve(self, nbytes):
         c = get()
-        if not c.kv_keep or nbytes > c.kv_keep_bytes or self.live + nbytes > c.kv_keep_total_bytes:
+        if not self.may_keep(nbytes) or self.live + nbytes > c.kv_keep_total_bytes:
             return None
         self.live += nbytes
         return _KeptBudget.Token(self, nbytes)

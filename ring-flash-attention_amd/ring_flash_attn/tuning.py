@@ -19,8 +19,10 @@ bench.py calls both in its warm-up at N > 1 and reports them in its `comm` block
 stand-alone version.  The record is a tuning cache (like a GEMM autotuner's): written once per shape under a lock,
 read-only afterwards; it never holds tensors.
 """
+import collections
 import threading
 import time
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -30,8 +32,30 @@ from . import config, utils
 _LOCK = threading.Lock()
 _TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
 _REPORTS = {}        # same key -> the measurement (for bench.py / logs)
-_AGREED = set()      # (group instance, key): the group has established that every rank holds the SAME record (or none)
+_PENDING = {}        # key -> form: a record installed by hand AFTER the group agreed on the key; waits for sync_records()
+# group instance -> the keys on which that group has established that every rank holds the SAME record (or none).  What a
+# rank finds here decides whether it POSTS the agreement all-reduce, so the set may only change in ways every rank of the
+# group repeats: agreed_lookup / autotune_zigzag_exchange / sync_records (collectives) add and drop entries, and the
+# per-group bound evicts in insertion order — the same order on every rank, which all make the same collective calls on a
+# group in the same sequence.  A rank-local event (record(), a tuning file read by some ranks) never touches it.
+_AGREED = {}
+_AGREED_MAX = 1024   # keys per group (sequence lengths that vary from step to step must not grow the set for ever)
 _CODES = {None: 0, "gather": 1, "ring": 2}
+
+
+def _is_agreed(ginst, key) -> bool:
+    return key in _AGREED.get(ginst, ())
+
+
+def _set_agreed(ginst, key):
+    d = _AGREED.setdefault(ginst, collections.OrderedDict())
+    d[key] = True
+    while len(d) > _AGREED_MAX:
+        d.popitem(last=False)
+
+
+_GROUP_SERIAL = {}   # (group name, id) -> (weak reference to the group object, serial)
+_SERIAL = [0]
 
 
 def _group_key(group):
@@ -47,12 +71,23 @@ def _group_key(group):
 
 
 def _group_instance(group):
-    """identity of this INSTANCE of the group (a group re-created after a restart of some ranks agrees again)"""
+    """identity of this INSTANCE of the group: a group re-created after destroy_process_group() (a restart of some ranks,
+    a test that re-initialises) gets the old one's name ('0' for WORLD) and possibly its `id()` — and must agree again.
+    So the identity is a serial number handed to the group OBJECT, found again through a weak reference to it."""
     try:
         g = dist.group.WORLD if group is None else group
-        return getattr(g, "group_name", None) or id(g)
+        k = (getattr(g, "group_name", None), id(g))
+        ent = _GROUP_SERIAL.get(k)
+        if ent is not None and ent[0]() is g:
+            return ent[1]
+        _SERIAL[0] += 1
+        _GROUP_SERIAL[k] = (weakref.ref(g), _SERIAL[0])
+        if len(_GROUP_SERIAL) > 64:
+            for k_ in [k_ for k_, e_ in _GROUP_SERIAL.items() if e_[0]() is None]:
+                _AGREED.pop(_GROUP_SERIAL.pop(k_)[1], None)
+        return _SERIAL[0]
     except Exception:
-        return id(group)
+        return ("unidentified", id(group))
 
 
 def _key(world, q_shape, k_shape, dtype, group=None):
@@ -67,14 +102,30 @@ def lookup(q_shape, k_shape, dtype, world, group=None):
 
 
 def record(q_shape, k_shape, dtype, world, form, group=None):
-    """install a record by hand (a tuning file, a test).  It decides a call only after `agreed_lookup` has established
-    that every rank of the group holds the same one."""
+    """install a record by hand (a tuning file, a test) — a RANK-LOCAL act, so it must not change which collectives this
+    rank posts (dropping the agreement here made a rank that loaded a tuning file late post an all-reduce its
+    peers never joined).  Before the group's first use of the key the record is simply stored: `agreed_lookup` then
+    establishes, collectively, whether every rank holds the same one.  Once the group HAS agreed on the key, the new
+    record is parked and the agreed state (record or none) keeps deciding until every rank calls `sync_records(group)`."""
     if form not in ("gather", "ring"):
         raise ValueError(f"exchange form must be gather or ring, got {form!r}")
     key = _key(world, q_shape, k_shape, dtype, group)
     with _LOCK:
-        _TUNED[key] = form
-        _AGREED.discard((_group_instance(group), key))
+        if _is_agreed(_group_instance(group), key):
+            _PENDING[key] = form
+        else:
+            _TUNED[key] = form
+
+
+def sync_records(group=None):
+    """COLLECTIVE (every rank of `group` calls it, at the same point of the program): records parked by `record()` are
+    installed and the group's agreements are dropped, so that the next use of each key re-agrees — on every rank alike,
+    because every rank dropped them here.  No communication happens in this call."""
+    ginst, gkey = _group_instance(group), _group_key(group)
+    with _LOCK:
+        for key in [k_ for k_ in _PENDING if k_[0] == gkey]:
+            _TUNED[key] = _PENDING.pop(key)
+        _AGREED.pop(ginst, None)
 
 
 def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
@@ -87,8 +138,8 @@ def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
     `autotune_zigzag_exchange` are agreed by construction (it is a collective).  Not under stream capture (the result
     could not be read back): there only an already agreed record is used."""
     key = _key(world, q_shape, k_shape, dtype, group)
-    inst = (_group_instance(group), key)
-    if inst in _AGREED:
+    ginst = _group_instance(group)
+    if _is_agreed(ginst, key):
         return _TUNED.get(key)
     if utils._loopback() is not None or utils.single_rank(world):
         return _TUNED.get(key)             # (nobody to agree with; a one-rank group forced onto the multi-step path — the
@@ -108,7 +159,7 @@ def agreed_lookup(q_shape, k_shape, dtype, world, group, device):
                 sys.stderr.write(f"ring_flash_attn: exchange record {key} is not shared by every rank of the group: ignored\n")
             _TUNED.pop(key, None)
             _REPORTS.pop(key, None)
-        _AGREED.add(inst)
+        _set_agreed(ginst, key)
     return _TUNED.get(key)
 
 
@@ -150,6 +201,7 @@ def clear():
     with _LOCK:
         _TUNED.clear()
         _REPORTS.clear()
+        _PENDING.clear()
         _AGREED.clear()
         _FAILED.clear()
 
@@ -174,8 +226,12 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
 
     world = group_rank_world(group)[1]
     key = _key(world, q.shape, k.shape, q.dtype, group)
-    if key in _TUNED:
-        return _REPORTS[key]
+    # Early return only on GROUP-CONSISTENT state: a report exists (only this collective writes one, on every rank) for a
+    # key the group has agreed on.  A record installed by hand (`record()`: rank-local, no report) never lets a rank skip
+    # the measurement its peers are inside — it is measured over.
+    rep = _REPORTS.get(key)
+    if rep is not None and _is_agreed(_group_instance(group), key):
+        return rep
     dev = q.device
     # scratch data from a PRIVATE generator: the caller's default RNG stream must not depend on whether, or in which
     # order, shapes were measured
@@ -222,7 +278,8 @@ def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "
     with _LOCK:
         _TUNED[key] = chosen
         _REPORTS[key] = rep
-        _AGREED.add((_group_instance(group), key))       # a collective measurement: every rank recorded this winner
+        _PENDING.pop(key, None)
+        _set_agreed(_group_instance(group), key)         # a collective measurement: every rank recorded this winner
     if config.get().tuning_log and dist.get_rank(group) == 0:
         import sys
 

@@ -15,6 +15,7 @@ same method names and error behaviour, re-designed for RCCL over xGMI:
   eager TorchScript ops; the schedules in this package do not even call it — they use the
   merge fused into the attention epilogue — it is kept for API parity.
 """
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -76,12 +77,23 @@ _BACKEND_OF = {}
 
 
 def backend_of(process_group) -> str:
-    """the group's torch.distributed backend name, resolved ONCE per group (not a `dist.get_backend()` per transfer)"""
+    """the group's torch.distributed backend name, resolved ONCE per group OBJECT (not a `dist.get_backend()` per
+    transfer).  The entry holds a weak reference to the group it was resolved for: after destroy_process_group() and a
+    re-init in the same process (tests; a bench that switches gloo -> nccl) WORLD gets the name '0' again and `id()` values
+    are recycled — an entry whose group object is gone, or is another object, is resolved anew."""
     g = dist.group.WORLD if process_group is None else process_group
     key = (getattr(g, "group_name", None), id(g))
-    b = _BACKEND_OF.get(key)
-    if b is None:
-        b = _BACKEND_OF[key] = str(dist.get_backend(process_group))
+    ent = _BACKEND_OF.get(key)
+    if ent is not None and ent[0]() is g:
+        return ent[1]
+    b = str(dist.get_backend(process_group))
+    try:
+        _BACKEND_OF[key] = (weakref.ref(g), b)
+    except TypeError:                      # (a group type that cannot be weakly referenced: resolved per call)
+        pass
+    if len(_BACKEND_OF) > 64:              # dead entries of destroyed groups
+        for k_ in [k_ for k_, e_ in _BACKEND_OF.items() if e_[0]() is None]:
+            del _BACKEND_OF[k_]
     return b
 
 

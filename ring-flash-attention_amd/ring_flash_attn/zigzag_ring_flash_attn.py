@@ -109,7 +109,13 @@ def _try_keep(keep, bufs, process_group):
         return
     if bufs[0].is_cuda and torch.cuda.is_current_stream_capturing():
         return                      # (the flag cannot be read back inside a capture; every rank captures alike)
-    token = config.kept_budget.try_reserve(sum(b_.numel() * b_.element_size() for b_ in bufs))
+    nbytes = sum(b_.numel() * b_.element_size() for b_ in bufs)
+    if not config.kept_budget.may_keep(nbytes):
+        # refused by the configuration and the call's size alone (kv_keep off, or this call over kv_keep_bytes): the same
+        # answer on every rank, so nothing to agree on — no all-reduce, no pinned allocation, no event per layer;
+        # `keep.agreed` stays None and the backward gathers again
+        return
+    token = config.kept_budget.try_reserve(nbytes)
     if token is not None:
         keep.extend(bufs)
         keep.token = token

@@ -90,6 +90,28 @@ def run(rank, W, port, ret):
     tuning.clear()
     tuning.record(qs, ks, q.dtype, W, "ring")
     res["record_everywhere"] = fwd_bwd()
+    # (4) ADVICE r5: the group HAS agreed on the key (the call above); now ONE rank installs a record late (a tuning file
+    #     it loads lazily).  That rank-local act must not change which collectives the rank posts: the agreed record
+    #     keeps deciding (no agreement all-reduce that only rank 0 would join — the timeout is the detector) ...
+    if rank == 0:
+        tuning.record(qs, ks, q.dtype, W, "gather")
+    res["late_record_rank0"] = fwd_bwd()
+    res["late_record_rank0"]["mine_after"] = tuning.lookup(qs, ks, q.dtype, W)
+    #     ... until every rank calls sync_records(): the parked record is installed, the group re-agrees at its next use,
+    #     finds the ranks' records differ and falls back to the shape rule (gather) everywhere
+    tuning.sync_records(None)
+    res["after_sync_records"] = fwd_bwd()
+    res["after_sync_records"]["mine_after"] = tuning.lookup(qs, ks, q.dtype, W)
+    tuning.clear()
+    # (5) ADVICE r5: a hand-installed record on ONE rank and then the collective measurement: no rank may return early
+    #     (there is no report to return — it was a KeyError — and its peers would wait inside the measurement)
+    if rank == 0:
+        tuning.record(qs, ks, q.dtype, W, "ring")
+    k_, v_ = kv.detach()[:, :, 0], kv.detach()[:, :, 1]
+    rep = tuning.autotune_zigzag_exchange(None, q.detach(), k_, v_, iters=1, warm=0)
+    rep2 = tuning.autotune_zigzag_exchange(None, q.detach(), k_, v_, iters=1, warm=0)      # now agreed + reported: returned as is
+    res["autotune_after_local_record"] = fwd_bwd()
+    res["autotune_after_local_record"]["mine_after"] = (rep["chosen"], rep2 is rep, tuning.lookup(qs, ks, q.dtype, W))
     tuning.clear()
 
     def same(a, b):

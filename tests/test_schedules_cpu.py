@@ -100,11 +100,19 @@ def test_collective_sequence_survives_rank_local_state(W):
             assert r[name]["posted"] == kept_path and r[name]["same_as_keep"], (name, r[name])
             assert r[name]["mine_after"] in (None, "-")
         assert set(r["record_everywhere"]["posted"]) == {"hop"}, r["record_everywhere"]
+        # a record installed on one rank AFTER the group agreed is parked (the agreed "ring" keeps deciding, on
+        # every rank) until the collective sync_records(); then the ranks' records differ and the shape rule decides
+        assert set(r["late_record_rank0"]["posted"]) == {"hop"} and r["late_record_rank0"]["mine_after"] == "ring", r["late_record_rank0"]
+        assert r["after_sync_records"]["posted"] == kept_path and r["after_sync_records"]["mine_after"] is None, r["after_sync_records"]
+        chosen, cached, mine = r["autotune_after_local_record"]["mine_after"]
+        assert chosen in ("gather", "ring") and cached and mine == chosen, r["autotune_after_local_record"]
+        assert set(r["autotune_after_local_record"]["posted"]) == ({"hop"} if chosen == "ring" else set(kept_path))
     # the ranks that could keep did save their buffers (6 saved tensors), the loser not (5): the DECISION was the group's
     for loser in range(W):
         assert [res[r][f"budget_rank{loser}"]["n_saved"] for r in range(W)] == [5 if r == loser else 6 for r in range(W)]
     assert [res[r]["held_graph"]["n_saved"] for r in range(W)] == [5] + [6] * (W - 1)
     assert res[0]["record_rank0_only"]["mine_after"] is None
+    assert len({r["autotune_after_local_record"]["mine_after"][0] for r in res}) == 1      # one winner for the whole group
 
 
 def test_bench_launches_its_own_ranks():
