@@ -582,7 +582,7 @@ def main():
                          "the *_varlen / llama3 ones mirror benchmark_varlen_kvpacked_func.py")
     ap.add_argument("--forward-only", action="store_true",
                     help="time the forward alone under torch.no_grad() (benchmark_kvpacked_func.py:85-96)")
-    ap.add_argument("--exchange", default=None, choices=["auto", "gather", "ring"],
+    ap.add_argument("--exchange", default=None, choices=["auto", "gather", "gather_ps", "ring"],
                     help="dense zigzag exchange form (default: RFA_ZIGZAG_EXCHANGE or auto)")
     ap.add_argument("--wire", default=None, choices=["io", "fp32"], help="dK/dV dtype on the wire (gather form)")
     ap.add_argument("--virtual-world", type=int, default=0,
@@ -592,6 +592,10 @@ def main():
     ap.add_argument("--no-autotune", action="store_true",
                     help="N > 1, dense zigzag, exchange 'auto': skip the measured choice between the exchange forms "
                          "(ring_flash_attn.tuning.autotune_zigzag_exchange in the warm-up) and use the shape rule")
+    ap.add_argument("--exchange-check-steps", type=int, default=0,
+                    help="N > 1: run this many UNTIMED steps with ring_flash_attn.config.exchange_check on before the warm-up — "
+                         "every K/V and dK/dV buffer a rank receives is checksummed against its sender (one extra tiny "
+                         "all-gather per schedule call); a mismatch ends the run naming rank / step / buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="always time one whole iteration (the default does unless the host is predicted to need more than 120 s)")
     ap.add_argument("--cpu-baseline-budget-s", type=float, default=60.0,
@@ -741,6 +745,18 @@ def main():
         except Exception as e:           # the probe must never sink the benchmark
             probe_rep = {"error": f"{type(e).__name__}: {e}"}
 
+    # ---- N > 1, opt-in: the exchange audit for a few untimed steps (the first 8-GPU run is also the first execution of
+    # every RCCL ordering of the package: profiles/collect_scale.sh asks for 2).  A failure here is a wrong result, not a
+    # reporting problem: it propagates.
+    exchange_checked = 0
+    if multi and args.exchange_check_steps > 0:
+        with rfa_config.override(exchange_check=True):
+            for _ in range(args.exchange_check_steps):
+                step()
+            torch.cuda.synchronize()
+        exchange_checked = args.exchange_check_steps
+        counter[0] = 0
+
     # device spin-up (not a measurement knob): the MI355X needs some tens of milliseconds of load to leave
     # its idle clocks; without it the W warm-up steps (W x ~2 ms) end while the clocks are still ramping and
     # the timed region measures the ramp, not the kernels.  Untimed, bounded, reported in the JSON line.
@@ -834,6 +850,7 @@ def main():
             rfa_testing.set_loopback(None)
         result["comm"] = {
             "exchange": mode,
+            "exchange_check_steps_passed": exchange_checked,      # (--exchange-check-steps: audited, untimed steps before the warm-up)
             "dkv_wire": ("fp32" if (_wire_fp32() or mode == "ring") else "bf16") if wl == "zigzag" else None,
             "backend": dist.get_backend(),
             "world_size_observed": dist.get_world_size(),

@@ -133,8 +133,8 @@ typedef struct {
   /* Kernel form (tuning / tests; 0 = chosen by the library): RFA_FWD_8x32 = 8 waves x 32 query rows, two waves per SIMD
    * (csrc/rfa_fwd.hip: every head dim, windows, dropout; 256 query rows per workgroup — RFA_FWD_AUTO also launches the
    * same kernel with 4 waves / 128 rows on grids that would under-fill the chip, RFA_FWD_4x32 asks for that form wherever
-   * it exists: head dim 128 / 64, no window, no dropout); RFA_FWD_4x64 = 4 waves x 64 rows, one
-   * wave per SIMD (csrc/experiments/rfa_fwd64.hip: only in builds made with --with-fwd64, RFA_ERR_ARGS otherwise) */
+   * it exists: head dim 128 / 64, no window, no dropout).  Value 2 named a 4-wave x 64-row, one-wave-per-SIMD experiment
+   * that lost to the 8 x 32 form by 7 - 13 % in two rounds and was removed in round 6: RFA_ERR_ARGS. */
   int32_t fwd_form;
   /* ABI 5 — split-KV launches.  A call with few query rows and many keys (a llama3 head group at 2048 tokens per rank
    * against the gathered keys of 8 ranks: 256 key tiles per workgroup, half the CUs without one) is launched with the
@@ -148,7 +148,7 @@ typedef struct {
   int64_t total_q;
 } rfa_fwd_args;
 
-enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_4x64 = 2, RFA_FWD_4x32 = 3 };
+enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_RETIRED_2 = 2, RFA_FWD_4x32 = 3 };
 
 typedef struct {
   const void *dout, *out; /* (B,Sq,H,D) io dtype */

@@ -14,7 +14,7 @@
 # Output: gpurun_out/scale/<TAG>_*.json|txt — copy into profiles/.
 set -u
 N=${1:-8}
-TAG=${2:-r05}
+TAG=${2:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=$R/gpurun_out/scale
@@ -33,9 +33,12 @@ else
 fi
 # bench.py launches its own N ranks (torch.distributed.run on 127.0.0.1 and a free port): the driver's command line
 BENCH="python $R/bench.py --gpus $N"
-$BENCH --steps 50 --warmup 10 $CPUB > $OUT/${TAG}_bench_n${N}.json 2> $OUT/${TAG}_bench_n${N}.err
-for mode in gather ring; do
-  $BENCH --steps 50 --warmup 10 --exchange $mode --no-cpu-baseline > $OUT/${TAG}_bench_n${N}_${mode}.json 2>> $OUT/${TAG}_bench_n${N}.err
+# (round 6) every run first takes 2 AUDITED steps (--exchange-check-steps: each received K/V and dK/dV buffer checksummed
+# against its sender, ring_flash_attn.config.exchange_check) — this is the first execution of the RCCL orderings with more
+# than one rank, and a wrong exchange must fail with rank / step / buffer named instead of producing a fast wrong number
+$BENCH --steps 50 --warmup 10 --exchange-check-steps 2 $CPUB > $OUT/${TAG}_bench_n${N}.json 2> $OUT/${TAG}_bench_n${N}.err
+for mode in gather gather_ps ring; do
+  $BENCH --steps 50 --warmup 10 --exchange-check-steps 2 --exchange $mode --no-cpu-baseline > $OUT/${TAG}_bench_n${N}_${mode}.json 2>> $OUT/${TAG}_bench_n${N}.err
 done
 $PROBE > $OUT/${TAG}_xgmi_probe_n${N}.json 2> $OUT/${TAG}_xgmi_probe_n${N}.err
 rm -rf $OUT/trace

@@ -25,9 +25,6 @@ SELFTEST_SRC = os.path.join(ROOT, "tests", "native", "selftest.cpp")
 SELFTEST_BIN = os.path.join(ROOT, "tests", "native", "selftest")
 
 HIP_SOURCES = ["rfa_fwd.hip", "rfa_bwd.hip", "rfa_bigd.hip", "rfa_dqs.hip", "rfa_aux.hip"]
-# experiments that are NOT in the default build: the 4 x 64 forward form (measured slower than the 8 x 32 form in rounds
-# 3 and 4; `build.py lib --with-fwd64` compiles it in for its tests / tools)
-FWD64_SOURCE = os.path.join("experiments", "rfa_fwd64.hip")
 API_SOURCE = "rfa_api.cpp"
 HEADERS = ["rfa_common.hpp", "rfa_kernels.hpp", os.path.join(ROOT, "include", "rfa.h")]
 EXPORTS_MAP = "rfa_exports.map"          # linker version script: only rfa_* is bindable
@@ -68,19 +65,17 @@ def _run(cmd, cwd=None):
     subprocess.run(cmd, cwd=cwd, check=True)
 
 
-def build_lib(force=False, with_fwd64=False):
-    hip_sources = HIP_SOURCES + ([FWD64_SOURCE] if with_fwd64 else [])
+def build_lib(force=False):
+    hip_sources = HIP_SOURCES
     srcs = [os.path.join(CSRC, s) for s in hip_sources + [API_SOURCE]]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(CSRC, EXPORTS_MAP)]
-    extra = "fwd64" if with_fwd64 else ""
+    extra = ""
     if not force and not _stale(LIB, deps, extra):
         return LIB
     # the build id (rfa_build_id()): digest of exactly the sources that go into the binary
     build_id = _digest(deps, extra)[:16]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-fno-gpu-rdc", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wno-unused-result", "-Wno-inline-asm", f'-DRFA_BUILD_ID="{build_id}"']
-    if with_fwd64:
-        cmd += ["-DRFA_WITH_FWD64=1", "-I" + CSRC]
     cmd += [os.path.join(CSRC, s) for s in hip_sources]
     cmd += ["-x", "hip", os.path.join(CSRC, API_SOURCE)]
     cmd += ["-Wl,--version-script=" + os.path.join(CSRC, EXPORTS_MAP), "-o", LIB]
@@ -119,7 +114,7 @@ def main(argv):
     targets = [a for a in argv if not a.startswith("-")] or ["lib", "oracle"]
     for t in targets:
         if t == "lib":
-            build_lib(force, with_fwd64="--with-fwd64" in argv)
+            build_lib(force)
         else:
             {"oracle": build_oracle, "selftest": build_selftest}[t](force)
 

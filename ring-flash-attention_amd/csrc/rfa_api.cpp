@@ -52,18 +52,6 @@ inline bool drop_args_ok(float p, int window, int wl, int wr, int causal) {
 
 }  // namespace
 
-// forward kernel form.  The 4 x 64 form (one wave per SIMD, 64 query rows per wave: csrc/experiments/rfa_fwd64.hip) was
-// measured 7 - 13 % slower than the 8 x 32 form in two rounds and is NOT part of the default build any more
-// (build.py --with-fwd64 compiles it in, -DRFA_WITH_FWD64=1); without it a call that asks for it by name is refused.
-#ifndef RFA_WITH_FWD64
-#define RFA_WITH_FWD64 0
-#endif
-static bool fwd_use_4x64(const rfa_fwd_args* a) {
-  const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-  if (a->D != kHeadDim || win || a->dropout_p > 0.f) return false;
-  return a->fwd_form == RFA_FWD_4x64;
-}
-
 // the library is built with -fvisibility=hidden: the C ABI below (include/rfa.h) is everything a loader can bind —
 // no rfa::launch_* internals, no kernel stubs (tests/test_abi.py::test_library_exports_only_the_c_abi)
 #pragma GCC visibility push(default)
@@ -220,13 +208,8 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   }
   p.qrows = rows;
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
-  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x32) return RFA_ERR_ARGS;
+  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x32 || a->fwd_form == RFA_FWD_RETIRED_2) return RFA_ERR_ARGS;
   if (a->D > kHeadDim) return launch_status(launch_fwd_big(p, a->dtype, (hipStream_t)stream));
-#if RFA_WITH_FWD64
-  if (fwd_use_4x64(a)) return launch_status(launch_fwd64(p, a->dtype, (hipStream_t)stream));
-#else
-  if (fwd_use_4x64(a)) return RFA_ERR_ARGS;             // the experiment is not in this build
-#endif
   if (int rc2 = launch_fwd(p, a->dtype, (hipStream_t)stream)) return launch_status(rc2);
   if (ns > 1 && launch_combine(cb, a->dtype, (hipStream_t)stream)) return RFA_ERR_LAUNCH;
   return RFA_OK;

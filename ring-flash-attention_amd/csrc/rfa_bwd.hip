@@ -56,8 +56,8 @@
 #define RFA_KV_X_LOAD 1
 #endif
 #ifndef RFA_KV_X_LDS
-#define RFA_KV_X_LDS 1
-#endif
+#define RFA_KV_X_LDS 1       // 0: no fragment reads; 2 (round 6): only sub-tile 0 of the 256-key form reads its fragments — HALF the
+#endif                       // reads per MFMA, the upper bound of what a 64-keys-per-wave / one-wave-per-SIMD form could save
 #ifndef RFA_KV_X_VALU
 #define RFA_KV_X_VALU 1
 #endif
@@ -712,11 +712,11 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
         constexpr int kN = 2 * kNK;
         vec8<T> a[kN], w[kNK];
         auto fa = [&](int i) {
-          if (!RFA_KV_X_LDS) return kwr[i % kNK];
+          if (!RFA_KV_X_LDS || (RFA_KV_X_LDS == 2 && t0 == 1)) return kwr[i % kNK];
           return lds_read128<T>(lds_ptr(aq ^ ((i % kNK) << 5)) + (i < kNK ? kOffDo : 0) + toff);
         };
         auto fw = [&](int i) {
-          if (!RFA_KV_X_LDS) return kwr[i];
+          if (!RFA_KV_X_LDS || (RFA_KV_X_LDS == 2 && t0 == 1)) return kwr[i];
           return lds_read128<T>(lds_ptr(avp ^ (i << 5)));
         };
 #pragma unroll
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
           constexpr int kPer = Geo::kSwzRows;
           const int kv = (16 * ks2 % kPer) / 16;
           const int imm = (which ? 0 : kOffDo) + (16 * ks2 / kPer) * kPer * kRowBytes + toff;
-          if (!RFA_KV_X_LDS) return kwr[i % kNK];
+          if (!RFA_KV_X_LDS || (RFA_KV_X_LDS == 2 && t0 == 1)) return kwr[i % kNK];
           vec4<T> lo = lds_read_tr<T>(lds_ptr(tq[kv][0] ^ (dblk << 6)) + imm);
           vec4<T> hi = lds_read_tr<T>(lds_ptr(tq[kv][1] ^ (dblk << 6)) + imm);
           return concat<T>(lo, hi);

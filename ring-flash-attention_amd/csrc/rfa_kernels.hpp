@@ -152,8 +152,6 @@ struct MergeParams {
 };
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream);
-// 4 waves x 64 rows, one wave per SIMD (rfa_fwd64.hip): D == 128 exactly, no window, no dropout; 256 rows per workgroup
-int launch_fwd64(const FwdParams& p, int dtype, hipStream_t stream);
 int fwd_qrows_per_block();
 // head dims 129 .. 256 (rfa_bigd.hip): same parameter blocks; the launchers set their own nqblk / nkblk
 constexpr int kMaxHeadDim = 256;

@@ -14,6 +14,7 @@ inputs are the caller's LOCAL shard.
 import torch
 
 from ._common import _prep_qkv, _as_cu, draw_dropout_seed
+from .utils import audit_verify
 
 
 def _opaque(fn):
@@ -183,6 +184,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
             )
+            audit_verify(group, f"{name} forward")          # (config.exchange_check: a no-op otherwise)
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
             _hold_kept(ctx, keep)
             ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
@@ -206,6 +208,7 @@ def make_autograd_function(name, forward_impl, backward_impl, n_lead):
                 window_size=ctx.window_size, alibi_slopes=None, deterministic=ctx.deterministic, **extra,
             )
             _release_kept(ctx)
+            audit_verify(ctx.group, f"{name} backward")
             return (dq, dk, dv) + (None,) * (n_lead + 8)
 
     _Fn.__name__ = _Fn.__qualname__ = name
@@ -247,6 +250,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                 group, q, k, v, *lead, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
                 window_size=window_size, alibi_slopes=alibi_slopes, deterministic=False, **extra,
             )
+            audit_verify(group, f"{name} forward")          # (config.exchange_check: a no-op otherwise)
             ctx.save_for_backward(q, k, v, out, softmax_lse, *tensors_lead, *(keep or ()))
             _hold_kept(ctx, keep)
             ctx.n_lead_t, ctx.n_keep = len(tensors_lead), len(keep or ())
@@ -284,6 +288,7 @@ def make_packed_function(name, base_fn, forward_impl, backward_impl, n_lead, pac
                     view.copy_(g)
             grads = (dpacked,) if n_packed == 3 else (dq, dpacked)
             _release_kept(ctx)
+            audit_verify(ctx.group, f"{name} backward")
             return grads + (None,) * (n_lead + 8)
 
     _PFn.__name__ = _PFn.__qualname__ = name

@@ -37,6 +37,12 @@ from torch import Tensor
 from .backend import get_backend
 
 
+def _audit_verify(group, where):
+    from .utils import audit_verify
+
+    audit_verify(group, where)
+
+
 def _lse_shape(q: Tensor, varlen: bool):
     if varlen:
         return (q.shape[1], q.shape[0])                  # (H, T)
@@ -177,6 +183,7 @@ def sched_fwd(schedule: str, q: Tensor, k: Tensor, v: Tensor, cu_seqlens: Option
     fwd, _ = _SCHEDULES[schedule]
     out, lse = fwd(_group_of(group_name), q, k, v, *_lead(cu_seqlens, max_seqlen), softmax_scale=softmax_scale,
                    dropout_p=0.0, causal=causal, window_size=(-1, -1), alibi_slopes=None, deterministic=False)
+    _audit_verify(_group_of(group_name), f"{schedule} forward (compiled caller)")
     return out.contiguous(), lse.contiguous()
 
 
@@ -196,6 +203,7 @@ def sched_bwd(schedule: str, dout: Tensor, q: Tensor, k: Tensor, v: Tensor, out:
     dq, dk, dv = bwd(_group_of(group_name), dout, q, k, v, out, lse, *_lead(cu_seqlens, max_seqlen),
                      softmax_scale=softmax_scale, dropout_p=0.0, causal=causal, window_size=(-1, -1),
                      alibi_slopes=None, deterministic=False)
+    _audit_verify(_group_of(group_name), f"{schedule} backward (compiled caller)")
     return dq.contiguous(), dk.contiguous(), dv.contiguous()
 
 

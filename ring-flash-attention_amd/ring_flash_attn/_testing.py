@@ -14,6 +14,9 @@ and hands it to the product modules, which otherwise carry a single `None` test 
     force_steps(flag)         a one-rank group keeps the multi-step path of every schedule — exchange buffers,
                               collectives, side stream, fp32 accumulators — which is how the RCCL calls of the product
                               path get exercised on a one-GPU box (tests/test_gpu_rccl_world1.py, RFA_BENCH_FORCE_RCCL).
+    corrupt_receive(n)        with config.exchange_check on: the n-th audited receive of this process (0-based, counted over
+                              ring hops and per-source exchanges) is overwritten after it landed — what a wrongly recycled
+                              receive buffer looks like; the audit must name it (tests/test_schedules_cpu.py).
     allow_host_staging(flag)  device tensors on a gloo group travel through host memory (several test ranks sharing one
                               MI355X: tests/_ring_worker.py).  Without it such a call RAISES: the product transport is
                               RCCL, and gloo cannot move device memory.
@@ -27,6 +30,15 @@ class Hooks:
         self.loopback = None          # (rank, world) or None
         self.force_steps = False
         self.host_staging = False
+        self.corrupt_recv = None      # countdown to the audited receive that gets corrupted, or None
+
+    def corrupt(self, buf):
+        if self.corrupt_recv == 0:
+            flat = buf.view(-1)
+            flat[flat.numel() // 2] += 1
+            self.corrupt_recv = None
+        elif self.corrupt_recv is not None:
+            self.corrupt_recv -= 1
 
 
 def _hooks() -> Hooks:
@@ -56,6 +68,10 @@ def force_steps(flag=True):
 
 def allow_host_staging(flag=True):
     _hooks().host_staging = bool(flag)
+
+
+def corrupt_receive(n=0):
+    _hooks().corrupt_recv = None if n is None else int(n)
 
 
 def reset():

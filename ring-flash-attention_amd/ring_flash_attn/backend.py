@@ -409,11 +409,11 @@ def _set_dropout(a, dropout):
     a.q_pos_offset, a.k_pos_offset, a.head_offset = int(q0), int(k0), int(h0)
 
 
-_FWD_FORMS = {"auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x64": _C.FWD_4x64, "4x32": _C.FWD_4x32}
+_FWD_FORMS = {"auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x32": _C.FWD_4x32}
 
 
 def _fwd_form() -> int:
-    """config.fwd_form (RFA_FWD_FORM = 8x32 | 4x32 | 4x64, tuning / tests); auto: the library's choice"""
+    """config.fwd_form (RFA_FWD_FORM = 8x32 | 4x32, tuning / tests); auto: the library's choice"""
     return _FWD_FORMS[config.get().fwd_form]
 
 

@@ -10,7 +10,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 
 | field                     | environment variable            | default | meaning |
 |---------------------------|---------------------------------|---------|---------|
-| zigzag_exchange           | RFA_ZIGZAG_EXCHANGE             | auto    | dense zigzag exchange form: auto / gather / ring (zigzag_ring_flash_attn.py) |
+| zigzag_exchange           | RFA_ZIGZAG_EXCHANGE             | auto    | dense zigzag exchange form: auto / gather / gather_ps (per-source arrival) / ring (zigzag_ring_flash_attn.py) |
 | zigzag_varlen_exchange    | RFA_ZIGZAG_VARLEN_EXCHANGE      | ring    | packed zigzag exchange form: ring / gather |
 | dkv_wire_fp32             | RFA_DKV_WIRE                    | io      | gather form: dK/dV contributions travel in the io dtype (io) or fp32 |
 | gather_max_bytes          | RFA_GATHER_MAX_BYTES            | 4 GiB   | auto without a measurement: gather while its O(S_total) scratch stays below |
@@ -22,10 +22,11 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | bwd_ds_spill              | RFA_BWD_DS_SPILL                | 1       | 5-GEMM backward (dS hand-off) where eligible; 0: always the 7-GEMM form |
 | ds_spill_max_bytes        | RFA_DS_SPILL_MAX_BYTES          | 4.5 GiB | size of the ONE reusable dS scratch per device and stream; larger hand-offs run in head-group chunks |
 | ds_spill_max_frac         | RFA_DS_SPILL_MAX_FRAC           | 0.5     | ... and never more than this fraction of the memory free when it is first taken |
-| fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 (256 rows) / 4x32 (128 rows) / 4x64 (experiment build only) |
+| fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 (256 rows) / 4x32 (128 rows) |
 | dkdv_wide, dkdv_nsplit    | RFA_DKDV_WIDE, RFA_DKDV_NSPLIT  | unset   | dK/dV launch plan overrides (tuning / tests) |
 | fwd_kv_nsplit             | RFA_FWD_KV_NSPLIT               | 0       | split-KV forward launches: 0 chosen from the shapes, 1 off, 2..8 forced (tuning / tests) |
 | tuning_log                | RFA_TUNING_LOG                  | 0       | print autotune decisions on rank 0 |
+| exchange_check            | RFA_EXCHANGE_CHECK              | 0       | DEBUG: checksum every K/V and dK/dV buffer a rank receives against its sender's checksum (one extra tiny all-gather and a host read-back per schedule call; a mismatch raises naming rank / step / buffer: utils.audit_verify) |
 """
 import contextlib
 import dataclasses
@@ -89,6 +90,7 @@ class Config:
     dkdv_nsplit: int = 0         # 0 unset
     fwd_kv_nsplit: int = 0       # 0: chosen from the shapes; 1: never split; 2..8 forced
     tuning_log: bool = False
+    exchange_check: bool = False
 
     @staticmethod
     def from_env(env=None) -> "Config":
@@ -100,7 +102,7 @@ class Config:
             return raw if raw is not None and raw.strip() != "" else None
 
         if (r := get("RFA_ZIGZAG_EXCHANGE")) is not None:
-            c.zigzag_exchange = _choice("RFA_ZIGZAG_EXCHANGE", r, ("auto", "gather", "ring"))
+            c.zigzag_exchange = _choice("RFA_ZIGZAG_EXCHANGE", r, ("auto", "gather", "gather_ps", "ring"))
         if (r := get("RFA_ZIGZAG_VARLEN_EXCHANGE")) is not None:
             c.zigzag_varlen_exchange = _choice("RFA_ZIGZAG_VARLEN_EXCHANGE", r, ("ring", "gather"))
         if (r := get("RFA_DKV_WIRE")) is not None:
@@ -127,7 +129,7 @@ class Config:
         if (r := get("RFA_DS_SPILL_MAX_FRAC")) is not None:
             c.ds_spill_max_frac = _float("RFA_DS_SPILL_MAX_FRAC", r, 0.0, 1.0)
         if (r := get("RFA_FWD_FORM")) is not None:
-            c.fwd_form = _choice("RFA_FWD_FORM", r, ("auto", "8x32", "4x32", "4x64"))
+            c.fwd_form = _choice("RFA_FWD_FORM", r, ("auto", "8x32", "4x32"))
         if (r := get("RFA_DKDV_WIDE")) is not None:
             c.dkdv_wide = 1 if _bool("RFA_DKDV_WIDE", r) else 0
         if (r := get("RFA_DKDV_NSPLIT")) is not None:
@@ -136,6 +138,8 @@ class Config:
             c.fwd_kv_nsplit = _int("RFA_FWD_KV_NSPLIT", r)
         if (r := get("RFA_TUNING_LOG")) is not None:
             c.tuning_log = _bool("RFA_TUNING_LOG", r)
+        if (r := get("RFA_EXCHANGE_CHECK")) is not None:
+            c.exchange_check = _bool("RFA_EXCHANGE_CHECK", r)
         return c
 
 

@@ -30,7 +30,7 @@ import torch.distributed as dist
 from . import config, utils
 
 _LOCK = threading.Lock()
-_TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "ring"
+_TUNED = {}          # (group ranks, world, B, S, H, Hk, D, dtype) -> "gather" | "gather_ps" | "ring"
 _REPORTS = {}        # same key -> the measurement (for bench.py / logs)
 _PENDING = {}        # key -> form: a record installed by hand AFTER the group agreed on the key; waits for sync_records()
 # group instance -> the keys on which that group has established that every rank holds the SAME record (or none).  What a
@@ -40,7 +40,7 @@ _PENDING = {}        # key -> form: a record installed by hand AFTER the group a
 # group in the same sequence.  A rank-local event (record(), a tuning file read by some ranks) never touches it.
 _AGREED = {}
 _AGREED_MAX = 1024   # keys per group (sequence lengths that vary from step to step must not grow the set for ever)
-_CODES = {None: 0, "gather": 1, "ring": 2}
+_CODES = {None: 0, "gather": 1, "ring": 2, "gather_ps": 3}
 
 
 def _is_agreed(ginst, key) -> bool:
@@ -107,8 +107,8 @@ def record(q_shape, k_shape, dtype, world, form, group=None):
     peers never joined).  Before the group's first use of the key the record is simply stored: `agreed_lookup` then
     establishes, collectively, whether every rank holds the same one.  Once the group HAS agreed on the key, the new
     record is parked and the agreed state (record or none) keeps deciding until every rank calls `sync_records(group)`."""
-    if form not in ("gather", "ring"):
-        raise ValueError(f"exchange form must be gather or ring, got {form!r}")
+    if form not in ("gather", "gather_ps", "ring"):
+        raise ValueError(f"exchange form must be gather, gather_ps or ring, got {form!r}")
     key = _key(world, q_shape, k_shape, dtype, group)
     with _LOCK:
         if _is_agreed(_group_instance(group), key):
@@ -217,7 +217,7 @@ def _max_over_ranks(value, group, dev):
     return t.item()
 
 
-def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "ring")):
+def autotune_zigzag_exchange(group, q, k, v, iters=3, warm=1, modes=("gather", "gather_ps", "ring")):
     """Time fwd + bwd of zigzag_ring_flash_attn_func in every exchange form on tensors shaped like (q, k, v) and
     record the faster one.  Collective: every rank of `group` must call it with the same shapes.  Returns the
     report dict {"chosen", "ms": {form: ms per iteration, max over ranks}, "failed": {...}}."""

@@ -109,6 +109,98 @@ def _needs_host_staging(process_group, t: torch.Tensor) -> bool:
 
 
 # ---------------------------------------------------------------------------------------------
+# Opt-in exchange audit (config.exchange_check / RFA_EXCHANGE_CHECK=1; round 6).  Every multi-rank GPU
+# test of this repo moves data through gloo and the host; the RCCL orderings (side-stream commit / wait, the recycled
+# receive buffers, posting W - 1 exchanges at once) run with more than one rank for the first time on the first 8-GPU job.
+# With the audit on, every buffer handed to a transfer is checksummed by its SENDER (on the compute stream, before the
+# transfer is posted) and by its RECEIVER (right after the wait that publishes it, before the kernel that consumes it);
+# at the end of the schedule call the senders' checksums are all-gathered — ONE extra tiny collective per call, plus one
+# host read-back: a debug mode — and every arrival is compared with what its sender sent.  A mismatch raises with the
+# rank, the step and the buffer named; the first 8-GPU run then diagnoses itself instead of producing wrong gradients.
+# (Sums are not audited: a reduce-scatter has no single sender.)
+_AUDITS = {}
+_AUDIT_MAX = 1024            # entries per call (fixed size: the table's all-gather must not depend on a rank's own path)
+
+
+def _audit_on() -> bool:
+    return config.get().exchange_check and _loopback() is None
+
+
+def _cksum(t: torch.Tensor) -> torch.Tensor:
+    """two 64-bit sums over the buffer's BIT PATTERNS: plain and position-weighted (a shifted or permuted buffer changes
+    the second) — exact integer arithmetic, identical on sender and receiver whatever the device"""
+    x = t.detach()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    w = {2: torch.int16, 4: torch.int32, 8: torch.int64}.get(x.element_size(), torch.uint8)
+    v = x.view(w).flatten().to(torch.int64)
+    pos = torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 8191 + 1
+    return torch.stack([v.sum(), (v * pos).sum()])
+
+
+class _Audit:
+    def __init__(self, group):
+        self.group, self.sent, self.recv = group, [], []
+
+    def send(self, t) -> int:
+        self.sent.append(_cksum(t))
+        return len(self.sent) - 1
+
+    def reserve(self, n) -> int:
+        """n consecutive entries filled later (all-to-all: one per destination)"""
+        base = len(self.sent)
+        self.sent.extend([None] * n)
+        return base
+
+    def expect(self, idx, src, t, label):
+        self.recv.append((idx, src, _cksum(t), label))
+
+
+def _audit(group) -> "_Audit":
+    g = dist.group.WORLD if group is None else group
+    a = _AUDITS.get(id(g))
+    if a is None:
+        a = _AUDITS[id(g)] = _Audit(group)
+    return a
+
+
+def audit_verify(group, where: str):
+    """compare everything this rank received during the call `where` with what the senders sent (collective when the
+    audit is on: every rank of `group` calls it at the same point — the autograd Functions and the compiled-caller
+    operators do, after each schedule forward / backward).  No-op when config.exchange_check is off."""
+    g = dist.group.WORLD if group is None else group
+    a = _AUDITS.pop(id(g), None)
+    if a is None or not config.get().exchange_check:
+        return
+    if len(a.sent) > _AUDIT_MAX:
+        raise RuntimeError(f"ring_flash_attn exchange check: {len(a.sent)} transfers in one call (> {_AUDIT_MAX})")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = next((c.device for c in a.sent if c is not None), torch.device("cpu"))
+    on_host = backend_of(group) == "gloo"
+    table = torch.zeros((_AUDIT_MAX + 1, 2), dtype=torch.int64, device=dev)
+    table[0, 0] = len(a.sent)
+    for i, c in enumerate(a.sent):
+        if c is not None:
+            table[i + 1] = c
+    mine = table.cpu() if on_host else table
+    all_ = torch.empty((world,) + tuple(mine.shape), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(all_.view(-1, 2), mine, group=group)
+    all_ = all_.cpu()
+    counts = [int(all_[r, 0, 0]) for r in range(world)]
+    if len(set(counts)) != 1:
+        raise RuntimeError(f"ring_flash_attn exchange check ({where}): the ranks posted different numbers of transfers "
+                           f"{counts} — the collective sequence diverged")
+    bad = []
+    for idx, src, c, label in a.recv:
+        got, want = c.cpu(), all_[src, idx + 1]
+        if not torch.equal(got, want):
+            bad.append(f"{label}: received checksum {got.tolist()} != sender rank {src}'s {want.tolist()}")
+    if bad:
+        raise RuntimeError(f"ring_flash_attn exchange check FAILED on rank {rank} in {where}: " + "; ".join(bad[:8])
+                           + (f" (+ {len(bad) - 8} more)" if len(bad) > 8 else ""))
+
+
+# ---------------------------------------------------------------------------------------------
 # Side HIP stream for the exchange.  torch's RCCL process group orders a collective after the
 # *current* stream at the moment it is posted and makes the *current* stream wait in Work.wait();
 # by posting and waiting under an explicit per-device side stream, the dependencies between the
@@ -166,6 +258,8 @@ class RingComm:
         self._local = []           # (src, dst) pairs of the loopback measurement hook
         self._pool = {}            # recycled receive buffers, keyed by (slot, shape, dtype, device)
         self._side = None          # side stream the pending transfer was posted under (RCCL path)
+        self._audit = []           # (entry index, receive buffer) of the pending transfer (config.exchange_check)
+        self._nhops = 0
 
         self.send_rank = (self.rank + 1) % self.world_size
         self.recv_rank = (self.rank - 1) % self.world_size
@@ -201,6 +295,8 @@ class RingComm:
         if _loopback() is not None:
             self._local.append((to_send, res))
             return res
+        if _audit_on():
+            self._audit.append((_audit(self._process_group).send(to_send), res))
         if _needs_host_staging(self._process_group, to_send):
             host_send = to_send.detach().to("cpu")
             host_recv = torch.empty(res.shape, dtype=res.dtype, device="cpu")
@@ -249,6 +345,15 @@ class RingComm:
                 req.wait()
         for host_recv, dev in self._staged:
             dev.copy_(host_recv)
+        if _TEST is not None and _TEST.corrupt_recv is not None and self._audit:
+            _TEST.corrupt(self._audit[0][1])          # (tests: a receive buffer that something overwrote after it landed)
+        if self._audit:
+            # the ring neighbour posts its transfers in the same order: entry i of ITS table is what arrived here
+            src = (self.rank - 1) % self.world_size
+            for j, (idx, buf) in enumerate(self._audit):
+                _audit(self._process_group).expect(idx, src, buf, f"ring hop {self._nhops}, buffer {j} (from rank {src})")
+            self._audit = []
+        self._nhops += 1
         self._staged = []
         self._local = []
         self._reqs = None
@@ -301,12 +406,15 @@ class AllGatherComm:
     def __init__(self, group=None) -> None:
         self.group = group
         self.handles = []
+        self._audit = []           # (entry index, gathered output)  (config.exchange_check)
 
     def all_gather(self, output_tensor: torch.Tensor, input_tensor: torch.Tensor):
         if _loopback() is not None:
             world = _loopback()[1]
             output_tensor.view(world, -1).copy_(input_tensor.reshape(1, -1).expand(world, -1))
             return
+        if _audit_on():
+            self._audit.append((_audit(self.group).send(input_tensor), output_tensor))
         if _needs_host_staging(self.group, input_tensor):
             host_in = input_tensor.detach().to("cpu").contiguous()
             host_out = torch.empty(output_tensor.shape, dtype=output_tensor.dtype, device="cpu")
@@ -320,6 +428,95 @@ class AllGatherComm:
         for handle in self.handles:
             handle.wait()
         self.handles = []
+        if self._audit:
+            rank, world = group_rank_world(self.group)
+            for j, (idx, out) in enumerate(self._audit):
+                parts = out.reshape(world, -1)
+                for src in range(world):
+                    if src != rank:
+                        _audit(self.group).expect(idx, src, parts[src], f"all-gather {j}, slot of rank {src}")
+            self._audit = []
+
+
+class SourceArrivals:
+    """The K/V of every other rank, RECEIVED IN CONSUMPTION ORDER (round 6: the `gather_ps` exchange form of the dense
+    zigzag schedule).  One all-gather hands step 1 its K/V only when the LAST source has landed (7 x 32 MiB at W = 8 behind
+    a 0.52 ms local block); the reference's hop protocol lets step s start when hop s is in
+    (/root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:60-84, utils.py:121-138).  Here all W - 1 exchanges are
+    posted AT ONCE, in the order the steps consume them — exchange s: send the local K/V to rank r + s, receive those of
+    rank r - s, a permutation in which every rank drives one direct xGMI link — each as its own batched isend/irecv group
+    under the side stream, and `wait(s)` makes the compute stream wait for exchange s ONLY (the group's completion event):
+    step s starts when source (r - s) mod W has landed, while the later sources are still on the wire.  RCCL runs the
+    groups of one communicator in posting order, which IS the consumption order.
+
+    `outs[i][src]` receives tensor i of rank src (the own slot is not written: the schedules use the local tensors there)."""
+
+    def __init__(self, process_group):
+        self._group = process_group
+        self.rank, self.world_size = group_rank_world(process_group)
+        self._reqs = {}            # step -> list of Work
+        self._staged = {}          # step -> [(host_recv, device_dst)]  (gloo ranks sharing one GPU: tests)
+        self._side = None
+        self._audit = {}           # step -> [(entry index, receive buffer)]  (config.exchange_check)
+
+    def _peer(self, r):
+        r %= self.world_size
+        return dist.get_global_rank(self._group, r) if self._group is not None else r
+
+    def post(self, locals_, outs):
+        W, rank = self.world_size, self.rank
+        if _loopback() is not None:
+            for t, out in zip(locals_, outs):
+                for src in range(W):
+                    if src != rank:
+                        out[src].copy_(t)
+            return self
+        t0 = locals_[0]
+        # (audit: ONE entry per tensor — every destination receives the same bytes)
+        entries = [_audit(self._group).send(t) for t in locals_] if _audit_on() else None
+        staging = _needs_host_staging(self._group, t0)
+        sends = [t.detach().to("cpu") if staging else (t if t.is_contiguous() else t.contiguous()) for t in locals_]
+        side = comm_stream(t0.device) if _use_side_stream(self._group, t0) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(t0.device))       # the send data exists, the receive buffers are free
+        for s in range(1, W):
+            dst, src = self._peer(rank + s), (rank - s) % W
+            ops, staged = [], []
+            for snd, out in zip(sends, outs):
+                rcv = out[src]
+                if staging:
+                    host = torch.empty(rcv.shape, dtype=rcv.dtype, device="cpu")
+                    staged.append((host, rcv))
+                    rcv = host
+                ops.append(dist.P2POp(dist.isend, snd, dst, group=self._group))
+                ops.append(dist.P2POp(dist.irecv, rcv, self._peer(src), group=self._group))
+            if side is not None:
+                with torch.cuda.stream(side):
+                    self._reqs[s] = dist.batch_isend_irecv(ops)
+            else:
+                self._reqs[s] = dist.batch_isend_irecv(ops)
+            self._staged[s] = staged
+            if entries is not None:
+                self._audit[s] = [(e, out[src]) for e, out in zip(entries, outs)]
+        self._side = side
+        return self
+
+    def wait(self, step: int):
+        """the compute (current) stream waits for exchange `step` — and for nothing posted after it"""
+        for req in self._reqs.pop(step, ()):
+            req.wait()
+        for host, dev in self._staged.pop(step, ()):
+            dev.copy_(host)
+        pend = self._audit.pop(step, ())
+        if pend and _TEST is not None and _TEST.corrupt_recv is not None:
+            _TEST.corrupt(pend[0][1])
+        src = (self.rank - step) % self.world_size
+        for j, (idx, buf) in enumerate(pend):
+            _audit(self._group).expect(idx, src, buf, f"per-source exchange {step}, tensor {j} (from rank {src})")
+
+    def wait_all(self):
+        for s in sorted(self._reqs):
+            self.wait(s)
 
 
 def _sum_on_host(output, input_, group) -> _Work:
@@ -390,9 +587,28 @@ def all_to_all_async(output: torch.Tensor, input_: torch.Tensor, group=None) -> 
     if _loopback() is not None:
         output.copy_(input_)
         return _Work(None)
+    check = None
+    if _audit_on():
+        rank, world = group_rank_world(group)
+        a = _audit(group)
+        base = a.reserve(world)                      # entry base + j: the chunk this rank sends to rank j
+        for j, part in enumerate(input_.reshape(world, -1)):
+            a.sent[base + j] = _cksum(part)
+
+        def check():
+            for src, part in enumerate(output.reshape(world, -1)):
+                if src != rank:
+                    a.expect(base + rank, src, part, f"all-to-all chunk from rank {src}")
     if _needs_host_staging(group, input_):
         host_in = input_.detach().to("cpu").contiguous()
         host_out = torch.empty(output.shape, dtype=output.dtype, device="cpu")
         handle = dist.all_to_all_single(host_out, host_in, group=group, async_op=True)
-        return _Work(handle, after=lambda: output.copy_(host_out))
-    return _post(group, input_, lambda: dist.all_to_all_single(output, input_, group=group, async_op=True))
+
+        def land():
+            output.copy_(host_out)
+            if check is not None:
+                check()
+        return _Work(handle, after=land)
+    w = _post(group, input_, lambda: dist.all_to_all_single(output, input_, group=group, async_op=True))
+    w.after = check
+    return w

@@ -30,6 +30,11 @@ MI355X-first differences:
               Cost: scratch of W x (K,V) in the io dtype plus W x (dK,dV) contributions per rank — O(S_total)
               instead of O(S_total/W): 0.27 + 0.27 GB at W = 8, Hk = 8, S = 8192/rank (0.54 GB with fp32
               contributions), 4.3 + 4.3 GB at 128K tokens/rank.
+      gather_ps  (round 6) the gather form with PER-SOURCE arrival: the W - 1 K/V exchanges are posted at once, in
+              consumption order, each its own isend/irecv pair (utils.SourceArrivals), and step s waits for source
+              (r - s) mod W only — the reference's "step s starts when hop s has landed"
+              (zigzag_ring_flash_attn.py:60-84) without putting a hop on the critical path of every step.  Same kernels,
+              same scratch, same backward return path (one all-to-all) as `gather`; bit-identical results.
       auto    the form the library MEASURED to be faster on this group for these shapes (first multi-rank call on an
               RCCL group: tuning.autotune_zigzag_exchange, a collective decision); without a measurement gather while
               that scratch stays below config.gather_max_bytes (default 4 GiB), ring beyond — long contexts keep ring
@@ -45,7 +50,7 @@ import torch
 
 from . import _C, config
 from .backend import get_backend
-from .utils import Agreement, AllGatherComm, RingComm, all_to_all_async, reduce_scatter_async, single_rank
+from .utils import Agreement, AllGatherComm, RingComm, SourceArrivals, all_to_all_async, reduce_scatter_async, single_rank
 from ._api import make_autograd_function, make_dense_api, _grad_buffers
 from ._common import packed_pair, dropout_arg
 
@@ -130,24 +135,29 @@ def _kv_views(bufs, k, world):
     return bufs[0].view((world,) + tuple(k.shape)), bufs[1].view((world,) + tuple(k.shape))
 
 
-def _gather_kv(comm_group, k, v, world):
+def _gather_kv(comm_group, k, v, world, per_source=False):
     """posts the all-gather of k and v; returns (handle, bufs, k_all, v_all): `bufs` the gathered base buffers,
     *_all[(src rank)] views of them.  k and v that are the two halves of one packed kv tensor (kvpacked entry points)
     travel as that one buffer: one collective of twice the size instead of two, no contiguous copies; the per-rank
-    K / V are then strided views of the gathered buffer."""
-    gather = AllGatherComm(comm_group)
+    K / V are then strided views of the gathered buffer.
+    per_source (the `gather_ps` form): W - 1 exchanges posted in consumption order instead of the one collective — the
+    handle is a utils.SourceArrivals whose wait(step) waits for source (rank - step) mod W only; same buffers and views
+    (the own slot stays unwritten: the schedules use the local k / v there)."""
     kv = packed_pair(k, v)
     if kv is not None:
         kv_cat = torch.empty((world * kv.shape[0],) + tuple(kv.shape[1:]), dtype=kv.dtype, device=kv.device)
-        gather.all_gather(kv_cat, kv)
-        bufs = [kv_cat]
+        bufs, locals_ = [kv_cat], [kv]
     else:
         # (world*B, ...) for the collective (the concatenated form every backend accepts), (world, B, ...) to index
         k_cat = torch.empty((world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
         v_cat = torch.empty((world * v.shape[0],) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-        gather.all_gather(k_cat, k.contiguous())
-        gather.all_gather(v_cat, v.contiguous())
-        bufs = [k_cat, v_cat]
+        bufs, locals_ = [k_cat, v_cat], [k.contiguous(), v.contiguous()]
+    if per_source:
+        gather = SourceArrivals(comm_group).post(locals_, [b_.view((world,) + tuple(t_.shape)) for b_, t_ in zip(bufs, locals_)])
+    else:
+        gather = AllGatherComm(comm_group)
+        for b_, t_ in zip(bufs, locals_):
+            gather.all_gather(b_, t_)
     return (gather, bufs) + _kv_views(bufs, k, world)
 
 
@@ -183,14 +193,18 @@ def zigzag_ring_flash_attn_forward(
     out_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
     lse_acc = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, comm.world_size, q, process_group, v) == "gather":
-        gather, bufs, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size)
-        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the all-gather
+    mode = exchange_mode(k, comm.world_size, q, process_group, v)
+    if mode in ("gather", "gather_ps"):
+        gather, bufs, k_all, v_all = _gather_kv(process_group, k, v, comm.world_size, per_source=mode == "gather_ps")
+        be.fwd(q, k, v, softmax_scale=softmax_scale, causal=True,          # runs beside the exchange
                out_acc=out_acc, lse_acc=lse_acc, acc_init=True)
-        gather.wait()
+        if mode == "gather":
+            gather.wait()                                                  # one collective: everything or nothing
         _try_keep(keep, bufs, process_group)
         for step in range(1, comm.world_size):
             src = (comm.rank - step) % comm.world_size
+            if mode == "gather_ps":
+                gather.wait(step)                                          # source (r - step) has landed; later ones fly on
             ks, vs = k_all[src], v_all[src]
             if step <= comm.rank:
                 be.fwd(q, ks[:, :half], vs[:, :half], softmax_scale=softmax_scale, causal=False,
@@ -266,13 +280,15 @@ def zigzag_ring_flash_attn_backward(
 
     dq = torch.empty((B, S, H, D), dtype=torch.float32, device=q.device)
 
-    if exchange_mode(k, kv_comm.world_size, q, process_group, v) == "gather":
+    mode = exchange_mode(k, kv_comm.world_size, q, process_group, v)
+    if mode in ("gather", "gather_ps"):
         W, rank = kv_comm.world_size, kv_comm.rank
         wire32 = _wire_fp32()
+        per_source = mode == "gather_ps"
         if kept:
             gather, (k_all, v_all) = None, _kv_views(kept, k, W)
         else:
-            gather, _, k_all, v_all = _gather_kv(process_group, k, v, W)
+            gather, _, k_all, v_all = _gather_kv(process_group, k, v, W, per_source=per_source)
         # K/V of every rank are here already: remote steps first, local block beside the all-to-all (the fp32
         # reduce-scatter wire keeps the local-first order)
         local_last = gather is None and not wire32
@@ -304,13 +320,15 @@ def zigzag_ring_flash_attn_backward(
         if not local_last:
             be.bwd(dout, q, k, v, softmax_lse, delta, softmax_scale=softmax_scale, causal=True,
                    dq_acc=dq, acc_init=True, deterministic=deterministic, **slots(rank, full))   # beside the all-gather
-            if gather is not None:
+            if gather is not None and not per_source:
                 gather.wait()
         elif rank == 0:
             dq[:, :half].zero_()             # every remote step of rank 0 covers the second half of the queries only
         first = local_last                   # the first kernel that touches dq initialises the rows it covers
         for step in range(1, W):
             src = (rank - step) % W
+            if gather is not None and per_source:
+                gather.wait(step)            # (a backward that gathers again: the remote steps consume in arrival order too)
             ks, vs = k_all[src], v_all[src]
             init, first = first, False
             if step <= rank:

@@ -17,7 +17,7 @@ for p in (ROOT, os.path.join(ROOT, "ring-flash-attention_amd")):
         sys.path.insert(0, p)
 
 
-def run(rank, W, port, ret):
+def run(rank, W, port, ret, form="gather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.pop("RFA_ZIGZAG_EXCHANGE", None)
     dist.init_process_group("gloo", rank=rank, world_size=W)
@@ -58,8 +58,8 @@ def run(rank, W, port, ret):
         return dict(out=out.detach().clone(), dq=q_.grad.clone(), dkv=kv_.grad.clone(), posted=list(posted), n_saved=n_saved)
 
     res = {}
-    with config.override(zigzag_exchange="gather"):
-        both_keep = fwd_bwd()
+    with config.override(zigzag_exchange=form):          # gather (one collective) or gather_ps (per-source arrival): the same
+        both_keep = fwd_bwd()                             # K/V hand-over logic and collective sequence (`_gather_kv` is counted)
         with config.override(kv_keep=False):
             none_keep = fwd_bwd()
         # (1) ONE rank's budget of kept bytes is exhausted (an output held on that rank only, say): it cannot keep,

@@ -62,10 +62,15 @@ def main(port):
 
     from ring_flash_attn import config
 
-    for mode in ("gather", "ring"):
+    for mode in ("gather", "ring", "gather_ps"):
         for wire in ("io", "fp32"):
             with config.override(zigzag_exchange=mode, dkv_wire_fp32=wire == "fp32"):
                 dense_case(R.zigzag_ring_flash_attn_func, f"zigzag[{mode},{wire}]")
+    # the exchange audit on the RCCL group (device-resident checksum table, all-gather on the group, host read-back)
+    with config.override(zigzag_exchange="ring", exchange_check=True):
+        dense_case(R.zigzag_ring_flash_attn_func, "zigzag[ring, exchange_check]")
+    with config.override(exchange_check=True):
+        dense_case(R.ring_flash_attn_func, "ring.causal[exchange_check]")
     dense_case(R.ring_flash_attn_func, "ring.causal")
     dense_case(R.ring_flash_attn_func, "ring.full", causal=False)
     dense_case(R.stripe_flash_attn_func, "stripe")

@@ -424,40 +424,6 @@ def test_bench_cpu_baseline_times_a_whole_iteration(single_rank_group, monkeypat
         sys.modules.update(saved)
 
 
-def test_fwd64_owns_its_accumulator_registers(tmp_path):
-    """csrc/experiments/rfa_fwd64.hip (not in the default build: build.py lib --with-fwd64) keeps O and Q in accumulator registers a64 .. a255 that only its inline asm touches.  hipcc
-    uses free accumulator registers (from a0 upwards) as spill space for arch VGPRs: audit the generated code — no
-    compiler-issued v_accvgpr_* (outside ;;#ASMSTART / ;;#ASMEND) may name a register above a63, and nothing may go
-    to scratch (cdna_hip_programming.md section 5.7 item 4)."""
-    import re
-    import shutil
-    import subprocess
-
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    src = os.path.join(ROOT, "ring-flash-attention_amd", "csrc", "experiments", "rfa_fwd64.hip")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "ring-flash-attention_amd", "csrc"),
-                        "-c", src, "-o", str(tmp_path / "x.o"),
-                        "-Wno-inline-asm", "-save-temps=obj"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    asm = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
-    assert asm
-    text = open(tmp_path / asm[0]).read()
-    inasm, bad, mfma = False, [], 0
-    for line in text.splitlines():
-        if "ASMSTART" in line:
-            inasm = True
-        elif "ASMEND" in line:
-            inasm = False
-        elif "v_mfma" in line:
-            mfma += 1
-        if not inasm and "v_accvgpr" in line and any(int(m) > 63 for m in re.findall(r"\ba(\d+)\b", line)):
-            bad.append(line.strip())
-    assert mfma >= 2 * 5 * 32, "both dtype instances with their pipelined loops"
-    assert not bad, f"the compiler touches the kernel's accumulator registers: {bad[:5]}"
-    assert re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text) and \
-        all(int(x) == 0 for x in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)), "scratch in use"
-
-
 def test_wide_head_dim_kernels_fit_the_register_file(tmp_path):
     """csrc/rfa_bigd.hip runs one wave per SIMD so that a 256-wide row's fragments and accumulators fit the 512-entry
     register file; a kernel that starts spilling to scratch inside its tile loop would still be correct and several times

@@ -11,10 +11,10 @@ def test_defaults_and_environment(monkeypatch):
     assert (c.zigzag_exchange, c.zigzag_varlen_exchange, c.dkv_wire_fp32, c.autotune, c.bwd_ds_spill) == ("auto", "ring", False, False, True)
     assert c.kv_keep and c.kv_keep_bytes == c.kv_keep_total_bytes == 4 << 30 and not hasattr(c, "force_steps")
     c = config.Config.from_env({"RFA_ZIGZAG_EXCHANGE": "Ring", "RFA_DKV_WIRE": "fp32", "RFA_ZIGZAG_KV_CACHE": "0",
-                                "RFA_DKDV_NSPLIT": "3", "RFA_FWD_FORM": "4x64", "RFA_DS_SPILL_MAX_FRAC": "0.25",
+                                "RFA_DKDV_NSPLIT": "3", "RFA_FWD_FORM": "4x32", "RFA_DS_SPILL_MAX_FRAC": "0.25",
                                 "RFA_FWD_KV_NSPLIT": "1"})
     assert (c.zigzag_exchange, c.dkv_wire_fp32, c.kv_keep, c.dkdv_nsplit, c.fwd_form, c.ds_spill_max_frac, c.fwd_kv_nsplit) == \
-        ("ring", True, False, 3, "4x64", 0.25, 1)
+        ("ring", True, False, 3, "4x32", 0.25, 1)
     monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather")           # (tests/conftest.py re-resolves on RFA_* changes)
     assert config.get().zigzag_exchange == "gather"
     monkeypatch.delenv("RFA_ZIGZAG_EXCHANGE")

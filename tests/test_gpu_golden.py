@@ -54,7 +54,7 @@ def test_schedules_under_torch_compile_at_world_size_gt_1_on_the_hip_kernels(W, 
     monkeypatch.setenv("RFA_TEST_COMPILE", "1")
     names = [n for n, c in MG.CASES.items() if c["W"] == W]        # (incl. the head-dim-128 multi-tile cases: the LDS-DMA instances)
     assert names
-    for mode in ("gather", "ring"):
+    for mode in ("gather", "ring", "gather_ps"):
         monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
         sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
         errs = RW.run_world(W, sel, use_hip=True, port=free_port())

@@ -23,7 +23,7 @@ def test_every_schedule_runs_its_exchange_on_rccl_world_size_1():
     assert "ALL OK" in r.stdout
 
 
-@pytest.mark.parametrize("workload,exchange", [("zigzag", "gather"), ("zigzag", "ring"), ("llama3", None)])
+@pytest.mark.parametrize("workload,exchange", [("zigzag", "gather"), ("zigzag", "ring"), ("zigzag", "gather_ps"), ("llama3", None)])
 def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
     """bench.py's N > 1 branches (RCCL init with device_id, barrier + all_reduce(MAX) on device tensors, the
     fixed-count spin-up, the loopback `comm` block) on a one-rank RCCL group: one JSON line, with the block"""
@@ -39,6 +39,8 @@ def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
     cmd += ["--cpu-baseline-budget-s", "1"] if exchange == "gather" else ["--no-cpu-baseline"]
     if exchange:
         cmd += ["--exchange", exchange]
+    if exchange in ("gather_ps", "ring"):
+        cmd += ["--exchange-check-steps", "2"]       # the audited steps of profiles/collect_scale.sh
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -46,6 +48,7 @@ def test_bench_multi_rank_branches_on_rccl_world_size_1(workload, exchange):
     d = json.loads(lines[0])
     assert d["forced_rccl_world1"] and d["comm"]["backend"] == "nccl" and d["comm"]["compute_only_ms"] > 0
     assert d["value"] > 0 and d["n_gpus"] == 1
+    assert d["comm"]["exchange_check_steps_passed"] == (2 if exchange in ("gather_ps", "ring") else 0)
     if exchange == "gather":
         cb = d["cpu_baseline"]
         assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 2 and "gloo CPU processes" in cb["sample"]

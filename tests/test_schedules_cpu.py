@@ -75,8 +75,8 @@ def test_kept_kv_is_owned_by_the_autograd_graph():
 
 
 @pytest.mark.timeout(400)
-@pytest.mark.parametrize("W", [2, 4])
-def test_collective_sequence_survives_rank_local_state(W):
+@pytest.mark.parametrize("W,form", [(2, "gather"), (4, "gather"), (3, "gather_ps")])
+def test_collective_sequence_survives_rank_local_state(W, form):
     """the keep / re-gather choice of the zigzag gather form reads a process-local byte budget, the
     exchange form a process-local tuning record — ranks whose local state disagrees must still post the SAME collectives.
     W gloo ranks; one rank's budget exhausted (by configuration — every rank in turn —, and by a graph only rank 0 keeps
@@ -87,7 +87,7 @@ def test_collective_sequence_survives_rank_local_state(W):
 
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(CW.run, args=(W, free_port(), ret), nprocs=W, join=True)
+    mp.spawn(CW.run, args=(W, free_port(), ret, form), nprocs=W, join=True)
     res = [ret[r] for r in range(W)]
     kept_path = ["all_gather", "all_to_all"]                        # forward gathers; the backward only returns dK/dV
     regather_path = ["all_gather", "all_gather", "all_to_all"]      # ... and gathers K/V a second time
@@ -105,7 +105,7 @@ def test_collective_sequence_survives_rank_local_state(W):
         assert set(r["late_record_rank0"]["posted"]) == {"hop"} and r["late_record_rank0"]["mine_after"] == "ring", r["late_record_rank0"]
         assert r["after_sync_records"]["posted"] == kept_path and r["after_sync_records"]["mine_after"] is None, r["after_sync_records"]
         chosen, cached, mine = r["autotune_after_local_record"]["mine_after"]
-        assert chosen in ("gather", "ring") and cached and mine == chosen, r["autotune_after_local_record"]
+        assert chosen in ("gather", "gather_ps", "ring") and cached and mine == chosen, r["autotune_after_local_record"]
         assert set(r["autotune_after_local_record"]["posted"]) == ({"hop"} if chosen == "ring" else set(kept_path))
     # the ranks that could keep did save their buffers (6 saved tensors), the loser not (5): the DECISION was the group's
     for loser in range(W):
@@ -113,6 +113,31 @@ def test_collective_sequence_survives_rank_local_state(W):
     assert [res[r]["held_graph"]["n_saved"] for r in range(W)] == [5] + [6] * (W - 1)
     assert res[0]["record_rank0_only"]["mine_after"] is None
     assert len({r["autotune_after_local_record"]["mine_after"][0] for r in res}) == 1      # one winner for the whole group
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("W", [2, 3])
+def test_exchange_check_names_a_corrupted_receive(W):
+    """the opt-in debug mode (config.exchange_check / RFA_EXCHANGE_CHECK=1) checksums every K/V and dK/dV
+    buffer a rank receives against its sender's checksum (utils.audit_verify: one extra tiny all-gather per schedule call).
+    Clean calls pass — bit-identical to the unchecked call — in all three zigzag exchange forms and in the ring / stripe
+    schedules; a receive buffer overwritten after it landed (ring_flash_attn._testing.corrupt_receive) makes THAT rank raise
+    with its rank, the step and the buffer named, its peers finish, and the next call is clean again."""
+    import torch.multiprocessing as mp
+    import _audit_worker as AW
+
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(AW.run, args=(W, free_port(), ret), nprocs=W, join=True)
+    for rank in range(W):
+        r = ret[rank]
+        for name in ("clean_ring", "clean_gather", "clean_gather_ps", "clean_ring_func", "clean_stripe_func", "after_ring", "after_gather_ps"):
+            assert r[name] is True, (rank, name, r)
+        if rank == W - 1:
+            assert f"FAILED on rank {rank}" in r["corrupt_ring"] and "ring hop" in r["corrupt_ring"] and "sender rank" in r["corrupt_ring"], r["corrupt_ring"]
+            assert f"FAILED on rank {rank}" in r["corrupt_gather_ps"] and "per-source exchange 1" in r["corrupt_gather_ps"], r["corrupt_gather_ps"]
+        else:
+            assert r["corrupt_ring"] == "no error" and r["corrupt_gather_ps"] == "no error", r
 
 
 def test_bench_launches_its_own_ranks():
@@ -305,6 +330,19 @@ def test_zigzag_ring_exchange_matches_golden(W, monkeypatch):
     assert not errs, "\n".join(errs)
 
 
+@pytest.mark.parametrize("W", [2, 3, 4, 8])
+def test_zigzag_per_source_arrival_matches_golden(W, monkeypatch):
+    """RFA_ZIGZAG_EXCHANGE=gather_ps (round 6): the gather form with the W - 1 K/V exchanges posted at
+    once in consumption order, step s waiting for source (r - s) mod W only (utils.SourceArrivals) — the reference's
+    "step s starts when hop s has landed" (/root/reference/ring_flash_attn/zigzag_ring_flash_attn.py:60-84).  Same
+    kernels, same merge order: the golden vectors of the unmodified reference, incl. an odd world size."""
+    monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", "gather_ps")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and c["kind"] == "zigzag"]
+    assert names
+    errs = RW.run_world(W, names, use_hip=False, port=free_port())
+    assert not errs, "\n".join(errs)
+
+
 @pytest.mark.parametrize("W", [2, 4])
 def test_schedules_under_torch_compile_at_world_size_gt_1(W, monkeypatch):
     """the reference's second test pass (test/test.sh:23-25: every test again with the function compiled, at the full
@@ -314,7 +352,7 @@ def test_schedules_under_torch_compile_at_world_size_gt_1(W, monkeypatch):
     monkeypatch.setenv("RFA_TEST_COMPILE", "1")
     names = [n for n, c in MG.CASES.items() if c["W"] == W and "sample" not in c]
     assert names
-    for mode in ("gather", "ring"):
+    for mode in ("gather", "ring", "gather_ps"):
         monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
         sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
         errs = RW.run_world(W, sel, use_hip=False, port=free_port())

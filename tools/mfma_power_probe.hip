@@ -13,6 +13,14 @@
 //                     magnitudes: what an attention kernel's Q / K / P / dO fragments look like to the matrix pipe)
 //     zero_rt         zeros LOADED at run time into the same 8 register pairs (control: the instruction stream and the
 //                     register allocation of `random`, the data of `zero` — separates the data from the code)
+// Round 6 ("the probe feeds a fresh random pair per MFMA, the worst toggling case; the kernels keep one
+// operand register-resident across MFMAs") — the operand RE-USE patterns of the attention kernels, all on random data:
+//     fresh           A and B both change at EVERY MFMA (the true worst case; `random` above holds B for two)
+//     holdB4          B held for 4 consecutive MFMAs, A fresh (the dV / dK and P V GEMMs: one P / dS operand x 4 d-blocks)
+//     holdB32         B held for the whole 32-MFMA block, A fresh
+//     holdA32         A held, B fresh (is the saving symmetric?)
+//     holdAB          one random pair for every MFMA (random bits, no operand change at all; accumulators still move)
+//     rand_x_zero     random A fresh, B = 0 (operand traffic without products)
 // while a thread samples the hwmon power of the GPUs (microwatts, the maximum over the cards = the one in use).  Prints
 // TFLOP/s, average watts and pJ per FLOP (after subtracting the idle floor measured first) per configuration.
 #include <hip/hip_runtime.h>
@@ -34,7 +42,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kAcc = 4;        // independent accumulators per wave (64 accumulator registers)
 constexpr int kOps = 8;        // operand register pairs rotated through
 
-// mode 0 zero, 1 const, 2 random, 3 zeros loaded at run time
+// mode 0 zero, 1 const, 2 random, 3 zeros loaded at run time, 4.. the round-6 re-use patterns (see the header)
 template <int kMode>
 __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float* sink, int iters) {
   const int tid = threadIdx.x + blockIdx.x * blockDim.x;
@@ -50,11 +58,12 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float*
         x = __uint_as_float(seed[1024 + ((tid + 8 * i + e) & 1023)]);
         y = __uint_as_float(seed[1024 + ((tid + 8 * i + e + 5) & 1023)]);
       }
-      if (kMode == 2) {
+      if (kMode == 2 || kMode >= 4) {
         s = s * 1664525u + 1013904223u;
         x = ((int)(s >> 8) % 4001 - 2000) * 0.001f;       // uniform in [-2, 2]: every mantissa / exponent bit toggles
         s = s * 1664525u + 1013904223u;
         y = ((int)(s >> 8) % 4001 - 2000) * 0.001f;
+        if (kMode == 9) y = __uint_as_float(seed[1024 + ((tid + 8 * i + e + 5) & 1023)]);      // zeros, opaque to the compiler
       }
       a[i][e] = (__bf16)x;
       b[i][e] = (__bf16)y;
@@ -66,9 +75,17 @@ __global__ __launch_bounds__(512, 2) void mfma_loop(const uint32_t* seed, float*
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 32; ++i)
-      acc[i % kAcc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % kOps], b[(i / 2) % kOps], acc[i % kAcc], 0, 0, 0);
-    if ((kMode == 2 || kMode == 3) && (it & 63) == 63) {
+    for (int i = 0; i < 32; ++i) {
+      int ia = i % kOps, ib = (i / 2) % kOps;                     // modes 0..3: the round-5 pattern
+      if (kMode == 4) ib = (3 * i + 1) % kOps;                    // fresh: both change every MFMA
+      if (kMode == 5) ib = (i / 4) % kOps;                        // holdB4
+      if (kMode == 6) ib = 0;                                     // holdB32
+      if (kMode == 7) { ia = 0; ib = i % kOps; }                  // holdA32
+      if (kMode == 8) { ia = 0; ib = 0; }                         // holdAB
+      if (kMode == 9) ib = (3 * i + 1) % kOps;                    // rand_x_zero (b[] holds zeros)
+      acc[i % kAcc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ia], b[ib], acc[i % kAcc], 0, 0, 0);
+    }
+    if (kMode >= 2 && (it & 63) == 63) {
       // keep the accumulators bounded (random products random-walk): fold them back, off the hot path
 #pragma unroll
       for (int i = 0; i < kAcc; ++i)
@@ -168,13 +185,19 @@ static void run(const char* name, int waves_per_simd, double seconds, const uint
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double flops = flop_per_iter * iters * (double)waves * launches;
   const double tf = flops / (ms * 1e-3) / 1e12;
-  printf("%-8s %d wave(s)/SIMD: %8.1f TFLOP/s  %7.1f W avg  %7.1f W peak  %6.3f pJ/FLOP all-in  %6.3f pJ/FLOP above the %.0f W floor  (%ld samples)\n",
+  printf("%-11s %d wave(s)/SIMD: %8.1f TFLOP/s  %7.1f W avg  %7.1f W peak  %6.3f pJ/FLOP all-in  %6.3f pJ/FLOP above the %.0f W floor  (%ld samples)\n",
          name, waves_per_simd, tf, w, smp.peak, w / (tf * 1e12) * 1e12, (w - idle_w) / (tf * 1e12) * 1e12, idle_w, smp.n);
   fflush(stdout);
 }
 
 int main(int argc, char** argv) {
+  // usage: mfma_power_probe [seconds] [modes: comma list or "all" | "r5" | "reuse"] [waves per SIMD: 1 | 2 | 12]
   const double seconds = argc > 1 ? atof(argv[1]) : 2.5;
+  std::string modes = argc > 2 ? argv[2] : "r5";
+  const int wsel = argc > 3 ? atoi(argv[3]) : 12;
+  if (modes == "r5") modes = "zero,const,random,zero_rt";
+  if (modes == "reuse") modes = "zero,random,fresh,holdB4,holdB32,holdA32,holdAB,rand_x_zero";
+  if (modes == "all") modes = "zero,const,random,zero_rt,fresh,holdB4,holdB32,holdA32,holdAB,rand_x_zero";
   Sampler smp;
   printf("power files: %zu\n", smp.files.size());
   std::vector<uint32_t> h(2048, 0u);
@@ -189,11 +212,19 @@ int main(int argc, char** argv) {
   std::this_thread::sleep_for(std::chrono::milliseconds(1000));
   const double idle_w = smp.stop();
   printf("idle floor: %.1f W\n", idle_w);
+  auto want = [&](const char* m) { return ("," + modes + ",").find(std::string(",") + m + ",") != std::string::npos; };
   for (int wps = 1; wps <= 2; ++wps) {
-    run<0>("zero", wps, seconds, seed, sink, smp, idle_w);
-    run<1>("const", wps, seconds, seed, sink, smp, idle_w);
-    run<2>("random", wps, seconds, seed, sink, smp, idle_w);
-    run<3>("zero_rt", wps, seconds, seed, sink, smp, idle_w);
+    if (wsel != 12 && wsel != wps) continue;
+    if (want("zero")) run<0>("zero", wps, seconds, seed, sink, smp, idle_w);
+    if (want("const")) run<1>("const", wps, seconds, seed, sink, smp, idle_w);
+    if (want("random")) run<2>("random", wps, seconds, seed, sink, smp, idle_w);
+    if (want("zero_rt")) run<3>("zero_rt", wps, seconds, seed, sink, smp, idle_w);
+    if (want("fresh")) run<4>("fresh", wps, seconds, seed, sink, smp, idle_w);
+    if (want("holdB4")) run<5>("holdB4", wps, seconds, seed, sink, smp, idle_w);
+    if (want("holdB32")) run<6>("holdB32", wps, seconds, seed, sink, smp, idle_w);
+    if (want("holdA32")) run<7>("holdA32", wps, seconds, seed, sink, smp, idle_w);
+    if (want("holdAB")) run<8>("holdAB", wps, seconds, seed, sink, smp, idle_w);
+    if (want("rand_x_zero")) run<9>("rand_x_zero", wps, seconds, seed, sink, smp, idle_w);
   }
   return 0;
 }
