@@ -4,6 +4,10 @@
 #include "../../include/rfa.h"
 #include "rfa_kernels.hpp"
 
+#include <algorithm>
+#include <atomic>
+#include <vector>
+
 using namespace rfa;
 
 namespace {
@@ -80,36 +84,179 @@ const char* rfa_strerror(int status) {
   }
 }
 
-// Split-KV plan of a forward call: shares of the key tiles per workgroup (1 = no split).  Grids of the 128-row form that
-// leave most of the chip's 512 workgroup slots (two 4-wave workgroups per CU) empty while every workgroup has a long
-// chain of key tiles (>= 64: about 1 us each, walked one after the other) are split until the slots are filled, each
-// share keeping at least 32 tiles (measured: 16-tile shares lose to the combine pass — S = 2048 self-attention with 16
-// heads 0.042 -> 0.044 ms — while a llama3 head group at 2048 rows against 16384 gathered keys gains 14 %).
-// Round 5 (profiles/r05_small_launch_fwd_forms.txt): when the 256-row grid has about HALF a workgroup per CU (112 .. 192
-// workgroups) and every workgroup a long chain of key tiles (>= 128), TWO shares of 256-row workgroups — one 8-wave
-// workgroup per CU, each K/V tile staged once for 256 rows — beat the 128-row form split the same way (twice the
-// workgroups, each tile staged for 128 rows: twice the L2 -> LDS traffic per MFMA): a llama3 head group at 2048 rows
-// against 16384 gathered keys 0.280 -> 0.268 ms, against 8192 keys 0.155 -> 0.151.
-static bool fwd_split_256_rows(const rfa_fwd_args* a) {
-  if (a->fwd_form != RFA_FWD_AUTO || a->kv_nsplit != 0 || a->D != kHeadDim) return false;
-  const int64_t wgs8 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + 255) / 256);
-  const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
-  return wgs8 >= 112 && wgs8 <= 192 && tiles >= 128 && eff_len(a->Sq, a->q_half) > 1024;
+// ---- launch plans (round 6: a cost estimate instead of shape thresholds) ------------------------------------------------
+// Rounds 2-5 chose the forward form and the dK/dV plan with constants found on a handful of shapes (`wgs8 >= 112 &&
+// wgs8 <= 192 && tiles >= 128`, `wgs128 * (ns + 1) <= 640`, `sq / (ns + 1) >= 2048`, ...).  tools/plan_sweep.py, which times
+// the chosen form against every form that can be forced on BOTH sides of those boundaries, found the cliffs the round-5
+// review predicted: forward launches of 96 / 160 / 192 / 224 workgroups against long key chains 8 - 26 % behind the best
+// form, and backward launches with 1 - 4 K/V heads (a llama3 head group, any GQA model with few K/V heads) up to 1.9 x
+// behind (profiles/r06_plan_sweep_before.md).  Both plans now come from ONE estimate of a launch's makespan:
+//     workgroups are jobs of `tiles + kPlanWgOverhead` tile-times (prologue, epilogue, fill / drain), dealt heaviest
+//     first (the kernels' blockIdx order) to the chip's 256 workgroup slots (one 8-wave workgroup per CU);
+//     makespan x (1 + 0.4 busy^2): the tile time grows with the fraction of the chip that is busy (the board clocks to
+//     its power cap: 1.33 us per forward tile with 96 CUs busy, 1.85 with 256 — profiles/r06_power_limiters.md);
+//     + kPlanSecondPass tile-times when the shares' partials need a second kernel (combine / reduce).
+// The plan is the candidate with the smallest estimate (ties: fewer shares).  A pure function of the call's shapes; the
+// result is memoised per shape (a 256-entry table of atomics: no lock, no allocation).
+// Fitted on / checked against tools/plan_sweep.py --dump (63 shapes x every forced form): worst chosen / best 1.06 where
+// the old rules reached 1.26 (forward) and 1.90 (backward); tests/test_gpu_plan_rules.py keeps it that way.
+namespace {
+
+constexpr int kPlanSlots = 256;            // CUs: one 8-wave workgroup each (LDS and registers allow no second one)
+constexpr double kPlanBusyGain = 0.4;
+
+// makespan of `n` jobs (sizes[i] tile-times each + ovh), heaviest first, on kPlanSlots equal machines; *work = sum of all
+double plan_makespan(std::vector<int>& sizes, double ovh, double* work) {
+  std::sort(sizes.begin(), sizes.end(), [](int x, int y) { return x > y; });
+  double total = 0;
+  for (int v : sizes) total += v + ovh;
+  *work = total;
+  if (sizes.empty()) return 0;
+  if ((int)sizes.size() <= kPlanSlots) return sizes[0] + ovh;
+  // min-heap of machine loads
+  std::vector<double> load(kPlanSlots, 0.0);
+  auto cmp = [](double x, double y) { return x > y; };
+  for (int v : sizes) {
+    std::pop_heap(load.begin(), load.end(), cmp);
+    load.back() += v + ovh;
+    std::push_heap(load.begin(), load.end(), cmp);
+  }
+  double mk = 0;
+  for (double l : load) mk = l > mk ? l : mk;
+  return mk;
 }
-static int fwd_kv_nsplit(const rfa_fwd_args* a) {
+double plan_cost(std::vector<int>& sizes, double ovh, double second_pass) {
+  double work = 0;
+  const double mk = plan_makespan(sizes, ovh, &work);
+  if (mk <= 0) return 0;
+  double busy = work / (mk * kPlanSlots);
+  busy = busy > 1 ? 1 : busy;
+  return mk * (1 + kPlanBusyGain * busy * busy) + second_pass;
+}
+
+// memo: (56-bit hash of the shape key) << 8 | plan code; 0 = empty
+std::atomic<uint64_t> g_plan_memo[256];
+inline uint64_t plan_hash(const int64_t* k, int n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+  for (int i = 0; i < n; ++i) {
+    h ^= (uint64_t)k[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xFF51AFD7ED558CCDull;
+    h ^= h >> 33;
+  }
+  h &= 0x00FFFFFFFFFFFFFFull;
+  return h ? h : 1;
+}
+inline bool plan_lookup(uint64_t h, int* code) {
+  const uint64_t w = g_plan_memo[h & 255].load(std::memory_order_relaxed);
+  if ((w >> 8) != h) return false;
+  *code = (int)(w & 255);
+  return true;
+}
+inline void plan_store(uint64_t h, int code) { g_plan_memo[h & 255].store((h << 8) | (uint64_t)(code & 255), std::memory_order_relaxed); }
+
+}  // namespace
+
+// Forward plan: query rows per workgroup (256 = 8 waves, 128 = 4 waves, two workgroups per CU) and split-KV shares.
+//   * many workgroups (>= 384 of 256 rows: 1.5 rounds of the chip and more): no shares; 128-row workgroups for sequences
+//     <= 1024 (+6 % at 1024, +13 % at 512, -2 % from 2048 on: round 4)
+//   * sequences <= 1024 otherwise: the 128-row form, shares by the round-4 rule (fill 512 slots + 25 %, >= 32 tiles each)
+//   * very few workgroups (<= 48 of 256 rows: one or two llama3 head groups) against >= 64 key tiles: the 128-row form,
+//     shares until 256 workgroups exist (>= 16 tiles each) — a lone 4-wave workgroup walks its tiles 1.4 x faster than an
+//     8-wave one does twice the rows (0.96 vs 1.33 us per tile), and there are CUs to spare
+//   * 257 .. 383 workgroups of 256 rows: the 128-row form, no shares (round 4's rule, confirmed by the round-6 sweep)
+//   * everything between: the 256-row form with the share count of the smallest estimated makespan
+struct FwdPlan { int rows, ns; };
+static FwdPlan fwd_plan(const rfa_fwd_args* a) {
+  FwdPlan pl{fwd_qrows_per_block(), 1};
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-  if ((a->D != kHeadDim && a->D != kHeadDim / 2) || win || a->dropout_p > 0.f) return 1;
-  if (a->kv_nsplit == 1 || a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return 1;
-  if (a->kv_nsplit > 1) return a->kv_nsplit > 8 ? 8 : a->kv_nsplit;      // (forced: with any named form, round 5)
-  if (a->fwd_form != RFA_FWD_AUTO) return 1;
-  if (fwd_split_256_rows(a)) return 2;
-  const int64_t wgs128 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + 127) / 128);
-  const int tiles = (eff_len(a->Sk, a->k_half) + 63) / 64;
-  if (wgs128 >= 384 || tiles < 64) return 1;
-  int ns = 1;
-  while (ns < 8 && wgs128 * (ns + 1) <= 640 && tiles / (ns + 1) >= 32) ++ns;
-  return ns;
+  if ((a->D != kHeadDim && a->D != kHeadDim / 2) || win || a->dropout_p > 0.f) return pl;   // one form, no shares
+  if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return pl;
+  const int sq = eff_len(a->Sq, a->q_half), sk = eff_len(a->Sk, a->k_half);
+  const int64_t w8 = (int64_t)a->B * a->H * ((sq + 255) / 256), w128 = (int64_t)a->B * a->H * ((sq + 127) / 128);
+  const int tiles = (sk + 63) / 64;
+  const bool can_split = a->kv_nsplit != 1;
+  // a form / share count asked for by name (tuning, tests) is taken as given
+  if (a->fwd_form == RFA_FWD_8x32 || a->fwd_form == RFA_FWD_4x32 || a->kv_nsplit > 1) {
+    pl.rows = a->fwd_form == RFA_FWD_4x32 ? 128 : 256;
+    pl.ns = a->kv_nsplit > 1 ? (a->kv_nsplit > 8 ? 8 : a->kv_nsplit) : 1;
+    if (a->fwd_form == RFA_FWD_AUTO) {                      // shares forced, form free: the form the rules below would take
+      rfa_fwd_args b = *a;
+      b.kv_nsplit = 0;
+      pl.rows = fwd_plan(&b).rows;
+    }
+    return pl;
+  }
+  if (w8 >= 384) {
+    pl.rows = sq <= 1024 ? 128 : 256;
+    return pl;
+  }
+  if (sq <= 1024) {
+    pl.rows = 128;
+    if (can_split && w128 < 384 && tiles >= 64) {
+      int ns = 1;
+      while (ns < 8 && w128 * (ns + 1) <= 640 && tiles / (ns + 1) >= 32) ++ns;
+      pl.ns = ns;
+    }
+    return pl;
+  }
+  if (w8 <= 48 && tiles >= 64) {
+    pl.rows = 128;
+    if (can_split) {
+      int ns = (int)(256 / w128);
+      ns = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+      while (ns > 1 && tiles / ns < 16) --ns;
+      pl.ns = ns;
+    }
+    return pl;
+  }
+  if (w8 > 256) {
+    // 257 .. 383 workgroups of 256 rows: one round of the chip plus a short second one.  The 128-row form (two workgroups
+    // per CU, a light one's partner speeds up when it leaves) balances that better than any share count of the 256-row
+    // form: S 6144, 12 heads, causal 0.130 vs 0.144 ms (round 4's rule for this range, kept: profiles/r06_plan_sweep_after.md)
+    pl.rows = 128;
+    return pl;
+  }
+  pl.rows = 256;
+  if (!can_split) return pl;
+  const int64_t key[8] = {1, a->B, a->H, sq, sk, a->causal ? 1 : 0, 0, 0};
+  const uint64_t h = plan_hash(key, 8);
+  int code;
+  if (plan_lookup(h, &code)) {
+    pl.ns = code;
+    return pl;
+  }
+  // workgroups of the 256-row form: block i of every (batch, head) sees the key tiles below its causal edge
+  const int off = sk - sq, nq = (sq + 255) / 256;
+  const int64_t mult = (int64_t)a->B * a->H;
+  double best = -1;
+  static const int cand[] = {1, 2, 3, 4, 6, 8};
+  for (int ns : cand) {
+    if (ns > 1 && tiles / ns < 16) continue;
+    std::vector<int> sizes;
+    sizes.reserve((size_t)(nq * ns * mult));
+    for (int i = 0; i < nq; ++i) {
+      const int qend = (i + 1) * 256 < sq ? (i + 1) * 256 : sq;
+      int kmax = sk;
+      if (a->causal && qend + off < kmax) kmax = qend + off;
+      const int nt = kmax > 0 ? (kmax + 63) / 64 : 0;
+      int chunk = (nt + ns - 1) / ns;
+      chunk = (chunk + 1) / 2 * 2;                           // (shares are a multiple of the LDS ring depth long: fwd_kernel)
+      for (int sidx = 0; sidx < ns; ++sidx) {
+        const int lo = sidx * chunk, hi = lo + chunk < nt ? lo + chunk : nt;
+        const int n = hi > lo ? hi - lo : 0;
+        for (int64_t m = 0; m < mult; ++m) sizes.push_back(n);
+      }
+    }
+    const double c = plan_cost(sizes, 8.0, ns > 1 ? 8.0 : 0.0);
+    if (best < 0 || c < 0.98 * best) {
+      best = c;
+      pl.ns = ns;
+    }
+  }
+  plan_store(h, pl.ns);
+  return pl;
 }
+static int fwd_kv_nsplit(const rfa_fwd_args* a) { return fwd_plan(a).ns; }
 static int64_t fwd_rows_total(const rfa_fwd_args* a) {
   if (a->cu_seqlens_q != nullptr) return a->total_q > 0 ? a->total_q : 0;
   return (int64_t)a->B * a->Sq;
@@ -165,25 +312,20 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   p.drop_scale = drop_rescale(a->dropout_p);
   p.drop_seed = a->dropout_seed;
   p.q_pos0 = (unsigned)a->q_pos_offset; p.k_pos0 = (unsigned)a->k_pos_offset; p.head0 = (unsigned)a->head_offset;
-  // 256 query rows per workgroup (8 waves) — or 128 (4 waves, two workgroups per CU) when the 8-wave grid would leave
-  // most of the 256 CUs without a workgroup (short per-rank chunks, few heads: llama3 head groups, the HF adapter)
-  int rows = fwd_qrows_per_block();
-  {
-    const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
-    const int64_t wgs8 = (int64_t)a->B * a->H * ((eff_len(a->Sq, a->q_half) + rows - 1) / rows);
-    if ((a->D == kHeadDim || a->D == kHeadDim / 2) && !win && !(a->dropout_p > 0.f) &&
-        (((wgs8 < 384 || eff_len(a->Sq, a->q_half) <= 1024) && a->fwd_form == RFA_FWD_AUTO) ||
-         a->fwd_form == RFA_FWD_4x32))      // (RFA_FWD_8x32 by name: always the 256-row form, RFA_FWD_4x32: the 128-row form
-      rows = 128;                           //  wherever it exists; sequences <= 1024: +6 % at 1024, +13 % at 512, -2 % from 2048 on)
-  }
+  // 256 query rows per workgroup (8 waves) or 128 (4 waves, two workgroups per CU), and the split-KV shares: fwd_plan()
+  const FwdPlan plan = fwd_plan(a);
+  int rows = plan.rows;
   // split-KV (needs the caller's workspace): the 128-row form with the key tiles of a workgroup shared by kv_nsplit
-  const int ns = (a->workspace != nullptr && fwd_rows_total(a) > 0) ? fwd_kv_nsplit(a) : 1;
+  const int ns = (a->workspace != nullptr && fwd_rows_total(a) > 0) ? plan.ns : 1;
   if (a->kv_nsplit < 0) return RFA_ERR_ARGS;
+  if (ns <= 1 && plan.ns > 1) {                              // planned with shares but called without a workspace: the unsplit plan
+    rfa_fwd_args b = *a;
+    b.kv_nsplit = 1;
+    rows = fwd_plan(&b).rows;
+  }
   CombineParams cb{};
   if (ns > 1) {
     if (!aligned16(a->workspace)) return RFA_ERR_ALIGN;
-    // shares of 128-row workgroups — of 256-row ones by name, or by the round-5 rule above
-    rows = (a->fwd_form == RFA_FWD_8x32 || fwd_split_256_rows(a)) ? fwd_qrows_per_block() : 128;
     const int64_t rt = fwd_rows_total(a);
     // partial layout: out (ns, rows_total, H, D) fp32, lse (ns, [B,] H, rows) fp32 behind it — addressed by the kernel
     // through the accumulate-mode fields (the call's own accumulators, if any, are the combine kernel's business)
@@ -253,6 +395,73 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 struct DkdvPlan { int wide, nsplit; };
 struct DsChunks { int nchunks, hc, gc; int64_t chunk_bytes; };     // hc K/V heads x gc query heads per K/V head per chunk
 static DsChunks bwd_ds_chunking(const rfa_bwd_args* a);
+// The dK/dV plan by estimated makespan (see "launch plans" above).  Jobs: one workgroup per (batch, K/V head, key block
+// [, share of its query tiles]); a key block that starts at key k0 walks the 64-row Q/dO tiles from its causal start
+// max(0, k0 - off) to the end of the sequence for each of the G query heads of its K/V head; `ns` workgroups take every
+// ns-th of those tiles.  The 128-key form has twice the workgroups, each tile-step with half the MFMAs but the same
+// LDS-DMA staging and barrier: 0.7 of the 256-key form's tile time (fitted).  Shares need the fp32 partials + reduce_kernel
+// pass: 12 tile-times.  Returns wide (0 / 1) and the share count; only_wide: the best share count of the 256-key form.
+// Packed (cu_seqlens) input: the sequences' lengths live on the device — the estimate takes B sequences of the mean
+// length total / B (bounded by max_seqlen), which is what the old rule's "about total_k / 256 key blocks" did.
+static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wide, int* ns_out) {
+  int sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
+  if (a->cu_seqlens_k != nullptr && a->total_k > 0 && a->B > 0) {
+    const int64_t mean_k = (a->total_k + a->B - 1) / a->B;
+    const int64_t mean_q = a->total_q > 0 ? (a->total_q + a->B - 1) / a->B : mean_k;
+    sk = (int)(mean_k < sk ? mean_k : sk);
+    sq = (int)(mean_q < sq ? mean_q : sq);
+    if (a->k_half != RFA_HALF_FULL) sk = (sk + 1) / 2;
+    if (a->q_half != RFA_HALF_FULL) sq = (sq + 1) / 2;
+  }
+  const int G = a->H / a->Hk;
+  const int64_t key[8] = {2, a->B, hk_launch, G, sq, sk, a->causal ? 1 : 0, (a->D == 64 ? 2 : 0) | (only_wide ? 1 : 0)};
+  const uint64_t h = plan_hash(key, 8);
+  int code;
+  if (plan_lookup(h, &code)) {
+    *ns_out = code & 15;
+    return code >> 4;
+  }
+  const int off = sk - sq;
+  const int64_t mult = (int64_t)a->B * hk_launch;
+  const int ntq = (sq + 63) / 64;
+  auto estimate = [&](int keys, int ns) {
+    const int nkb = (sk + keys - 1) / keys;
+    std::vector<int> sizes;
+    sizes.reserve((size_t)(nkb * ns * mult));
+    for (int kb = 0; kb < nkb; ++kb) {
+      int qfirst = a->causal ? kb * keys - off : 0;
+      qfirst = qfirst < 0 ? 0 : qfirst;
+      const int nt = ntq - qfirst / 64 > 0 ? ntq - qfirst / 64 : 0;
+      for (int sidx = 0; sidx < ns; ++sidx) {
+        const int n = nt > sidx ? (nt - 1 - sidx) / ns + 1 : 0;        // tiles nt-1-sidx, nt-1-sidx-ns, ... (dkdv_kernel)
+        for (int64_t m = 0; m < mult; ++m) sizes.push_back(n * G);
+      }
+    }
+    double work = 0;
+    const double mk = plan_makespan(sizes, 12.0, &work);
+    if (mk <= 0) return 0.0;
+    double busy = work / (mk * kPlanSlots);
+    busy = busy > 1 ? 1 : busy;
+    return mk * (keys == 128 ? 0.7 : 1.0) * (1 + kPlanBusyGain * busy * busy) + (ns > 1 ? 12.0 : 0.0);
+  };
+  double best = -1;
+  int wide = 0, best_ns = 1;
+  if (!only_wide) best = estimate(128, 1);
+  for (int ns = 1; ns <= 8; ++ns) {
+    if (ns == 5 || ns == 7) continue;
+    if (ns > 1 && (sq < 1024 ? ns > 2 : ntq / ns < 2)) continue;       // (shares of at least 2 tiles; short sequences: two at most)
+    const double c = estimate(256, ns);
+    if (best < 0 || c < 0.98 * best) {
+      best = c;
+      wide = 1;
+      best_ns = ns;
+    }
+  }
+  plan_store(h, (wide << 4) | best_ns);
+  *ns_out = best_ns;
+  return wide;
+}
+
 // hk_launch: K/V heads of ONE dK/dV launch (= Hk, or the K/V heads of a chunk of a chunked dS hand-off)
 static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
   DkdvPlan pl{0, 1};
@@ -274,27 +483,23 @@ static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
   }
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if (a->dkdv_form == RFA_DKDV_128 || (a->D != kHeadDim && a->D != 64) || win || a->dropout_p > 0.f) return pl;
-  const int64_t sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
-  // workgroups that receive work: packed input launches B * ceil(max_seqlen / 256) key blocks per K/V head, of which
-  // only about total_k / 256 (+ one tail per sequence) are not past the end of their sequence
-  int64_t kblocks = (int64_t)a->B * ((sk + 255) / 256);
-  if (a->cu_seqlens_k != nullptr && a->total_k > 0) {
-    const int64_t eff = (a->total_k + 255) / 256 + a->B;
-    kblocks = eff < kblocks ? eff : kblocks;
+  // a plan asked for by name (tuning, tests; the REDUCE half of a two-phase call repeats its COMPUTE half's plan)
+  if (a->dkdv_form == RFA_DKDV_256 || a->dkdv_nsplit > 0) {
+    pl.wide = 1;
+    if (a->dkdv_nsplit > 0) {
+      pl.nsplit = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
+    } else {
+      rfa_bwd_args b = *a;                                   // form forced, shares free: the count the estimate gives the 256-key form
+      b.dkdv_form = RFA_DKDV_AUTO;
+      int best_ns = 1;
+      (void)bwd_dkdv_cost_plan(&b, hk_launch, true, &best_ns);
+      pl.nsplit = best_ns;
+    }
+    return pl;
   }
-  const int64_t wgs = kblocks * hk_launch;
-  // Sharing a key block's query range between workgroups (fp32 partials + reduce_kernel) pays for the causal imbalance of
-  // LONG query ranges only: measured (profiles/r04_dkdv_plans_short_sequences.txt, B x S = 8192, Hk 8) S 1024: 0.374 ms
-  // with two shares, 0.341 with the 128-key form, 0.321 with unshared 256-key workgroups; S 2048: 0.591 / 0.572 / 0.585;
-  // S 4096: 0.872 / 0.862 / 1.060.  So: shares of >= 2048 rows; sequences <= 1024 take the 256-key form unshared
-  // whenever that still gives 160 workgroups; otherwise the 256-key form needs 320.
   int ns = 1;
-  while (ns < 4 && wgs * ns < 448 && sq / (ns + 1) >= 2048) ++ns;
-  const bool forced = a->dkdv_form == RFA_DKDV_256;
-  if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
-  if (!forced && a->dkdv_nsplit <= 0 && (sq <= 1024 ? wgs < 160 : wgs * ns < 320)) return pl;
-  pl.wide = 1;
-  pl.nsplit = ns;
+  pl.wide = bwd_dkdv_cost_plan(a, hk_launch, false, &ns);
+  pl.nsplit = pl.wide ? ns : 1;
   return pl;
 }
 static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {

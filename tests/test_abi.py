@@ -265,17 +265,23 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 8192, 8192, 32, 32)) == 0
     assert ws(args(1, 8192, 8192, 32, 32, acc=True)) == unit(8192, 32)
     assert ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_COMPUTE)) == ws(args(1, 8192, 8192, 32, 32, phases=_C.BWD_REDUCE))
-    # ring "front" step of world size 8 (all queries x 4096 keys): four workgroups per key block
-    assert ws(args(1, 8192, 4096, 32, 8)) == 4 * unit32(4096, 8)
-    # small launches, padded head dims and windows keep the 128-key form (no split, no workspace)
-    assert plan(args(1, 1024, 1024, 4, 2)) == (_C.DKDV_128, 1)
-    assert ws(args(1, 1024, 1024, 4, 2)) == 0
+    # ring "front" step of world size 8 (all queries x 4096 keys: 128 key-block workgroups): two shares each fill the
+    # chip in ONE round (round 6: chosen 1.437 ms = the best forced plan, profiles/r06_plan_sweep_after.md; rounds 2-5 ran 4)
+    assert plan(args(1, 8192, 4096, 32, 8)) == (_C.DKDV_256, 2)
+    assert ws(args(1, 8192, 4096, 32, 8)) == 2 * unit32(4096, 8)
+    # a launch with a handful of key blocks (4 x 2 K/V heads) is shared until the chip has work: round 6's sweep found such
+    # launches up to 1.9 x behind the best plan under the old "shares of >= 2048 rows" rule
+    assert plan(args(1, 1024, 1024, 4, 2)) == (_C.DKDV_256, 8)
+    assert ws(args(1, 1024, 1024, 4, 2)) == 8 * unit32(1024, 2)
+    # padded head dims and windows keep the 128-key form (no split, no workspace)
     assert ws(args(1, 8192, 8192, 32, 8, D=96)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=96)) == 0
     assert plan(args(1, 8192, 8192, 32, 8, D=56, causal=True)) == (_C.DKDV_128, 1)
     # head dim 64 exactly (round 5): the 256-key form by the same shape rules, never a dS hand-off
     assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == (_C.DKDV_256, 2)
-    assert ws(args(1, 8192, 8192, 32, 8, D=64)) == 2 * unit32(8192, 8, 64) and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
-    assert plan(args(1, 1024, 1024, 4, 2, D=64)) == (_C.DKDV_128, 1)
+    assert ws(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == 2 * unit32(8192, 8, 64) and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    # (no mask: 256 equal workgroups are one balanced round of the chip — nothing to share, no workspace)
+    assert plan(args(1, 8192, 8192, 32, 8)) == (_C.DKDV_256, 1) and ws(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert plan(args(1, 1024, 1024, 4, 2, D=64)) == (_C.DKDV_256, 8)
     assert ws(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0 and ds(args(1, 8192, 8192, 32, 8, window=(512, -1))) == 0
     # packed sequences: the form is chosen from the packed row count, and so is the scratch (ABI 5): total / 32 + B
     # query-block rows per head, each with the key blocks of the longest (half) sequence — 3.9 GB for the varlen
@@ -287,13 +293,15 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 8192, 8192, 32, 8, form=_C.DKDV_128)) == 0
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == (_C.DKDV_256, 3)
     assert ws(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == 3 * unit32(1024, 2)
-    assert plan(args(1, 4096, 4096, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 2)    # (split count still by shape)
-    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 1)    # (... shares of >= 2048 query rows)
-    # short sequences (profiles/r04_dkdv_plans_short_sequences.txt): <= 1024 the 256-key form unshared from 160 workgroups
-    # on; 2048 with 256 workgroups: the 128-key form; 4096: two shares
+    assert plan(args(1, 4096, 4096, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 8)    # (share count still by the estimate)
+    assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 8)
+    # short sequences with 8 K/V heads (profiles/r04_dkdv_plans_short_sequences.txt, re-measured in round 6): <= 1024 the
+    # 256-key form unshared; 2048 and 4096 with 256 workgroups: two shares (the causal imbalance of ONE round)
     assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_256, 1)
     assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_256, 1)
-    assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_128, 1)
+    assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    # the plan is a pure function of the shapes: asking twice (memoised) gives the same answer
     assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 2)
     # ... the process environment does not reach the library
     monkeypatch.setenv("RFA_DKDV_WIDE", "0")
@@ -346,8 +354,9 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
 
 def test_forward_split_plan_is_a_function_of_the_arguments(built):
     """rfa_fwd_workspace_bytes reports the split-KV plan of a forward call (no device needed): few rows against many key
-    tiles are split; round 5: a half-filled grid of 256-row workgroups with >= 128 key tiles takes two shares (of 256-row
-    workgroups: rfa_api.cpp fwd_split_256_rows); a named form never splits by itself, a forced share count always does"""
+    tiles are split; round 6: between 49 and 256 workgroups of 256 rows the share count is the one with the smallest estimated
+    makespan (rfa_api.cpp fwd_plan; tools/plan_sweep.py measures it against every forced form); a named form never splits by
+    itself, a forced share count always does"""
     from ring_flash_attn import _C
 
     lib = _C.load()
@@ -363,9 +372,12 @@ def test_forward_split_plan_is_a_function_of_the_arguments(built):
 
     assert plan(1, 8192, 8192, 32, 8) == 1                       # the headline: 1024 workgroups
     assert plan(1, 256, 4096, 4, 2) == 2                         # few rows, 64 tiles
-    assert plan(1, 2048, 16384, 16, 8) == 2 and plan(1, 2048, 8192, 16, 8) == 2      # llama3 head groups (round 5 rule)
-    assert plan(1, 2048, 4096, 16, 8) == 2                       # (64 tiles: the 128-row rule)
-    assert plan(1, 2048, 2048, 16, 8) == 1                       # short chains are not split
+    assert plan(1, 2048, 16384, 16, 8) == 2 and plan(1, 2048, 8192, 16, 8) == 2      # llama3 head groups: 128 workgroups -> 256
+    assert plan(1, 2048, 16384, 8, 4) == 4 and plan(1, 2048, 16384, 2, 1) == 8       # ... half a layer, one K/V head (128-row form)
+    assert plan(1, 2048, 4096, 16, 8) == 2
+    assert plan(1, 2048, 2048, 16, 8) == 2                       # 128 causal workgroups, 32 tiles at most: two shares of >= 16
+    assert plan(1, 2048, 1536, 16, 8) == 1                       # shares would be shorter than 16 tiles: not split
+    assert plan(1, 2048, 8192, 24, 6) == 1 and plan(1, 2048, 8192, 20, 5) in (1, 3)  # 160 .. 224 workgroups: never 1.25 rounds
     assert plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32) == 1 and plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32, nsplit=3) == 3
     assert plan(1, 2048, 16384, 16, 8, nsplit=1) == 1
     assert plan(1, 2048, 16384, 16, 8, D=96) == 1                # (head dims without the split forms)
