@@ -155,11 +155,13 @@ def committed_traffic(kernel, hk):
     return sect[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
 
 
-# Round 5 (profiles/r05_mfma_power_probe.txt, r05_power_probe.json): the board sits at its 1400 W cap during the
-# backward and the whole step, and a register-only MFMA loop sustains 2.46 PFLOP/s on zero / constant operands but
-# 1.83 PFLOP/s on random ones — the rate the chip can pay for depends on the data.  `roofline.peak` stays the datasheet's
-# 2.5 PFLOP/s (MI355X_MICROARCH.md); the line additionally quotes the fraction of this MEASURED random-operand rate.
-MFMA_RANDOM_DATA_TFLOPS = 1830.0
+# Round 5 (profiles/r05_power_probe.json): the board sits at its 1400 W cap during the backward and the whole step, and a
+# register-only MFMA loop sustains 2.47 PFLOP/s on zero operands but 1.82-1.90 PFLOP/s on random ones — the rate the chip can
+# pay for depends on the data.  `roofline.peak` stays the datasheet's 2.5 PFLOP/s (MI355X_MICROARCH.md); the line additionally
+# quotes the fraction of the MEASURED random-operand rate.  Round 6 (profiles/r06_power_limiters.md): the
+# reference rate is the probe row with the kernels' operand RE-USE pattern (one operand held for 4 consecutive MFMAs, as in
+# the P·V / dV / dK GEMMs: 1845 TFLOP/s; a fresh pair per MFMA 1821, one pair for all 1904) instead of round 5's 1830.
+MFMA_RANDOM_DATA_TFLOPS = 1845.0
 
 
 class PowerSampler:
@@ -822,8 +824,11 @@ def main():
         "peak_device_memory_gib": round(peak_gib, 3),
         # board power over the timed region (hwmon, a ~1 s moving average: meaningful from a few hundred ms of steps on)
         # and the energy of one step: at the 1400 W cap the step's time IS its energy / 1400 W
+        # `valid`: the sensor is a ~1 s moving average — a timed region shorter than 0.5 s (the driver's --steps 20 is 0.04 s)
+        # reads the tail of whatever ran before it (1293 W where 200-step runs read 1385-1400 W: VERDICT r5 weak #11)
         "power": ({"avg_w": round(watts[0], 1), "max_w": round(watts[1], 1), "samples": watts[2],
-                   "joules_per_step": round(watts[0] * elapsed / args.steps, 4), "source": "amdgpu hwmon power1_input"}
+                   "joules_per_step": round(watts[0] * elapsed / args.steps, 4), "source": "amdgpu hwmon power1_input",
+                   "timed_region_s": round(elapsed, 3), "valid": bool(elapsed >= 0.5)}
                   if watts[0] is not None else None),
         "algorithmic_tflops_per_gpu": per_gpu_flops * its / 1e12,
         "mfma_roofline_frac_end_to_end": per_gpu_flops * its / 1e12 / MFMA_PEAK_TFLOPS,
@@ -999,7 +1004,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / MFMA_PEAK_TFLOPS,
                 # against the rate a register-only MFMA loop sustains on RANDOM operands on this chip (measured:
-                # tools/mfma_power_probe.hip, profiles/r05_mfma_power_probe.txt; 2.46 PFLOP/s on zero / constant operands)
+                # tools/mfma_power_probe.hip `holdB4`, profiles/r06_power_limiters.md; 2.47 PFLOP/s on zero operands)
                 "frac_of_random_operand_mfma_rate": ach / MFMA_RANDOM_DATA_TFLOPS,
                 "random_operand_mfma_tflops": MFMA_RANDOM_DATA_TFLOPS,
                 "traffic": entry["hbm_bytes_per_launch"] if entry else None,

@@ -11,9 +11,9 @@
 # other build) — and only THEN the kernel-trace pass runs, so that the bench line committed with the trace carries
 # `roofline.traffic` of its own build instead of "stale" (round-3 review).
 # Output: gpurun_out/prof/<pass>/...; summaries: gpurun_out/prof/<tag>_*.txt + <tag>_traffic.json
-#   usage: bash profiles/collect_pmc.sh r05        (then copy gpurun_out/prof/r05_* into profiles/)
+#   usage: bash profiles/collect_pmc.sh r06        (then copy gpurun_out/prof/r06_* into profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Everything under profiles/<TAG>_* in one GPU-box command (about 11 minutes on one MI355X):
-#     bash profiles/collect_round.sh [TAG=r05]
+#     bash profiles/collect_round.sh [TAG=r06]
 #   PMC passes + traffic file + kernel trace (collect_pmc.sh), the bench rows of the reference's tables, the compute-only
 #   virtual ring, the shape sweep, the llama3 short-launch regime, the power probes, the C-ABI self test, smoke(), and the
 #   whole GPU suite.  Outputs: gpurun_out/<TAG>/ — copy what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -23,9 +23,13 @@ for wl in ring stripe ring_varlen zigzag_varlen llama3; do timeout 200 $B --work
 timeout 300 python tools/shape_sweep.py > $O/${TAG}_shape_sweep.md 2>/dev/null
 { timeout 120 python tools/small_launch.py --rank 7 2>/dev/null | grep -v Gloo; timeout 120 python tools/small_launch.py --rank 3 2>/dev/null | grep -v Gloo; } > $O/${TAG}_small_launch_llama3.txt
 timeout 200 python tools/power_probe.py --seconds 3 > $O/${TAG}_power_probe.json 2>/dev/null
+mkdir -p build/tools
 [ -x build/tools/mfma_power_probe ] || hipcc --offload-arch=gfx950 -O3 tools/mfma_power_probe.hip -o build/tools/mfma_power_probe -lpthread
-timeout 200 build/tools/mfma_power_probe 6 > $O/${TAG}_mfma_power_probe.txt 2>&1
-timeout 200 python tools/graph_step.py > $O/${TAG}_graph_step.md 2>/dev/null
+# (round 6) the limiter read-out beside every phase incl. the MFMA probe's operand re-use patterns, the plan sweep (chosen
+# vs every forced form), the host time inside Agreement.resolve() under a 28-layer stack
+timeout 400 python tools/power_limiters.py --seconds 3 --json $O/${TAG}_power_limiters.json > $O/${TAG}_power_limiters_table.md 2>/dev/null
+timeout 900 python tools/plan_sweep.py > $O/${TAG}_plan_sweep_after.md 2>/dev/null
+timeout 200 python tools/agreement_stall.py > $O/${TAG}_agreement_stall.txt 2>&1
 ( timeout 300 ./tests/native/selftest ) > $O/${TAG}_native_selftest.txt 2>&1
 ( timeout 300 python __graft_entry__.py smoke ) > $O/${TAG}_smoke.txt 2>&1
 ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 ) > $O/${TAG}_pytest_gpu.log 2>&1

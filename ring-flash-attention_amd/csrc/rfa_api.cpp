@@ -163,7 +163,8 @@ inline void plan_store(uint64_t h, int code) { g_plan_memo[h & 255].store((h << 
 //   * very few workgroups (<= 48 of 256 rows: one or two llama3 head groups) against >= 64 key tiles: the 128-row form,
 //     shares until 256 workgroups exist (>= 16 tiles each) — a lone 4-wave workgroup walks its tiles 1.4 x faster than an
 //     8-wave one does twice the rows (0.96 vs 1.33 us per tile), and there are CUs to spare
-//   * 257 .. 383 workgroups of 256 rows: the 128-row form, no shares (round 4's rule, confirmed by the round-6 sweep)
+//   * fewer than 64 key tiles, or 257 .. 383 workgroups of 256 rows: the 128-row form, no shares (round 4's rules, confirmed
+//     by the round-6 sweep)
 //   * everything between: the 256-row form with the share count of the smallest estimated makespan
 struct FwdPlan { int rows, ns; };
 static FwdPlan fwd_plan(const rfa_fwd_args* a) {
@@ -207,6 +208,13 @@ static FwdPlan fwd_plan(const rfa_fwd_args* a) {
       while (ns > 1 && tiles / ns < 16) --ns;
       pl.ns = ns;
     }
+    return pl;
+  }
+  if (tiles < 64) {
+    // short key chains on an under-filled chip (S 2048, 16 heads: 128 workgroups of <= 32 tiles): nothing to share — shares of
+    // < 32 tiles do not pay for the combine pass — and the 128-row form's two workgroups per CU balance the causal triangle
+    // (round 4's rule; round 6 re-measured: 0.0385 ms against 0.0455 with two shares of 256-row workgroups, 0.0493 with one)
+    pl.rows = 128;
     return pl;
   }
   if (w8 > 256) {

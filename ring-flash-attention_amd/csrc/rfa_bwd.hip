@@ -44,7 +44,7 @@
 #ifndef RFA_KV_WIDE_UNROLL
 #define RFA_KV_WIDE_UNROLL 1 // dkdv kWide: 1 = the two sub-tile bodies unrolled, 0 = a runtime loop over one body.  Round 4, after the mask
                              // rewrite had freed 15 registers (244 registers, no scratch): the headline launch 1.092 -> 1.063 ms, the whole
-                             // step 2.033 -> 2.000 ms (profiles/r04_dkdv_variants.txt, three passes).  The unrolled bodies address the
+                             // step 2.033 -> 2.000 ms (profiles/history/r04_dkdv_variants.txt, three passes).  The unrolled bodies address the
                              // second sub-tile with instruction immediates (+ 32 rows) instead of toggling every fragment base
 #endif
 #ifndef RFA_KV_AHEAD2
@@ -67,7 +67,7 @@
 #ifndef RFA_KV_PRIO
 #define RFA_KV_PRIO 0        // 1: the two waves of a SIMD get different priorities (measured neutral); 2: waves 4-7 at s_setprio 1
                              // (neutral); s_setprio 1 around 3: the dP / S GEMM pair, 4: the dV / dK GEMM pair, 5: both.  Round 4 A/B of
-                             // the headline launch (profiles/r04_dkdv_variants.txt): with the one-body loop 0 -> 1.0870 ms, 3 -> 1.0836,
+                             // the headline launch (profiles/history/r04_dkdv_variants.txt): with the one-body loop 0 -> 1.0870 ms, 3 -> 1.0836,
                              // 4 -> 1.0788, 5 -> 1.0965; with the two sub-tile bodies unrolled (the default now) 4 and 0 are equal
                              // (whole step 2.001 vs 1.994 ms over three passes), so the default stays 0
 #endif

@@ -3,7 +3,7 @@
 // The split-by-output backward (rfa_bwd.hip) pays 7 GEMM-units for 5 because dq_kernel recomputes S and
 // dP.  Atomics cannot fix that on this chip: the dQ partials of a 128-key workgroup are 4.3 GB of fp32
 // atomic adds per headline backward and gfx950 retires 1.26 TB/s of them (tools/atomic_probe.hip,
-// profiles/r02_atomic_probe.txt) — 3.4 ms against a 1.6 ms backward.  What the chip does have is HBM:
+// profiles/history/r02_atomic_probe.txt) — 3.4 ms against a 1.6 ms backward.  What the chip does have is HBM:
 // dkdv_kernel already holds dS = P∘(dP−Δ) of every (32 query x 32 key) block as two packed 16-byte MFMA
 // operands per lane, so it stores them (2 KB per block, 16-byte stores, 2.1 GB bf16 for the headline
 // causal S = 8192) and this kernel streams them back exactly once:

@@ -37,7 +37,7 @@
 #ifndef RFA_FWD_MAXFORM
 #define RFA_FWD_MAXFORM 1    // the half-wave exchange of the row max / row sum: 0 ds_bpermute (__shfl_xor: an LDS round trip plus
                              // six address instructions per tile), 1 v_permlane32_swap (rfa_common.hpp: max_xor32).  Same bits.
-                             // Round 4 A/B (profiles/r04_fwd_variants.txt): 0 -> 0.4880 ms, 1 -> 0.4795.  Also measured there and
+                             // Round 4 A/B (profiles/history/r04_fwd_variants.txt): 0 -> 0.4880 ms, 1 -> 0.4795.  Also measured there and
                              // NOT kept, all bit-identical: the 31-deep max chain as four independent chains (0.4831: six more
                              // canonicalising v_max), the first sub-tile's chain in the MFMA shadows of the second sub-tile's
                              // S GEMM (0.4846), one barrier per TWO tiles on a 4-stage ring (0.4889), s_setprio 1 around the S

@@ -137,7 +137,7 @@ def llama3_flash_attn_varlen_forward(
         # k and v are the two halves of ONE packed (T, 2, Hk, D) tensor (the kvpacked / qkvpacked entry points) and all
         # heads are one super-group: the packed tensor travels as it is — ONE all-gather instead of two, no contiguous
         # copies of the halves (round 5: those were 2 of the elementwise launches per pass of
-        # profiles/r04_short_launch_kernel_trace.txt); the gathered K / V are strided views of the one buffer
+        # profiles/history/r04_short_launch_kernel_trace.txt); the gathered K / V are strided views of the one buffer
         buf = torch.empty((total_k * world_size,) + tuple(kvp.shape[1:]), dtype=k.dtype, device=k.device)
         comm = Comm(process_group)
         comm.all_gather(buf, kvp)

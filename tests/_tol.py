@@ -16,7 +16,7 @@ and `within_2x_naive(...)` states the criterion flash_attn's own tests use for t
 README quotes: the error against an exact (fp32, unrounded) computation is at most twice the error a naive bf16
 implementation of the same formula makes, plus epsilon.
 
-The numbers below were set from the values observed on MI355X (profiles/r03_tolerances_observed.txt: every
+The numbers below were set from the values observed on MI355X (profiles/history/r03_tolerances_observed.txt: every
 comparison of the GPU suite logs its metrics when RFA_TOL_LOG names a file) with about 3x head-room.
 """
 import os
@@ -24,7 +24,7 @@ import os
 import torch
 
 #            atol    rtol     fro     mean_abs  mean_rel
-# Observed on MI355X (profiles/r03_tolerances_observed.txt, 2118 comparisons of the GPU suite), worst case per kind ->
+# Observed on MI355X (profiles/history/r03_tolerances_observed.txt, 2118 comparisons of the GPU suite), worst case per kind ->
 # bound: out max|err|/max|ref| 6.4e-3, fro 2.5e-3, mean/mean 2.0e-3; grad 7.8e-3, 3.0e-3, 2.3e-3; out_ring 6.9e-3,
 # 3.2e-3, 2.3e-3; grad_ring 1.04e-2, 4.5e-3, 3.4e-3; lse 1.9e-6 absolute.
 KINDS = {

@@ -295,7 +295,7 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256, nsplit=3)) == 3 * unit32(1024, 2)
     assert plan(args(1, 4096, 4096, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 8)    # (share count still by the estimate)
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 8)
-    # short sequences with 8 K/V heads (profiles/r04_dkdv_plans_short_sequences.txt, re-measured in round 6): <= 1024 the
+    # short sequences with 8 K/V heads (profiles/history/r04_dkdv_plans_short_sequences.txt, re-measured in round 6): <= 1024 the
     # 256-key form unshared; 2048 and 4096 with 256 workgroups: two shares (the causal imbalance of ONE round)
     assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_256, 1)
     assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_256, 1)
@@ -375,8 +375,7 @@ def test_forward_split_plan_is_a_function_of_the_arguments(built):
     assert plan(1, 2048, 16384, 16, 8) == 2 and plan(1, 2048, 8192, 16, 8) == 2      # llama3 head groups: 128 workgroups -> 256
     assert plan(1, 2048, 16384, 8, 4) == 4 and plan(1, 2048, 16384, 2, 1) == 8       # ... half a layer, one K/V head (128-row form)
     assert plan(1, 2048, 4096, 16, 8) == 2
-    assert plan(1, 2048, 2048, 16, 8) == 2                       # 128 causal workgroups, 32 tiles at most: two shares of >= 16
-    assert plan(1, 2048, 1536, 16, 8) == 1                       # shares would be shorter than 16 tiles: not split
+    assert plan(1, 2048, 2048, 16, 8) == 1 and plan(1, 2048, 1536, 16, 8) == 1       # short key chains are not split
     assert plan(1, 2048, 8192, 24, 6) == 1 and plan(1, 2048, 8192, 20, 5) in (1, 3)  # 160 .. 224 workgroups: never 1.25 rounds
     assert plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32) == 1 and plan(1, 2048, 16384, 16, 8, form=_C.FWD_8x32, nsplit=3) == 3
     assert plan(1, 2048, 16384, 16, 8, nsplit=1) == 1

@@ -216,10 +216,13 @@ def test_exchange_autotune_is_a_collective_decision(break_gather):
     assert a["chosen"] == b["chosen"] == a["after"] == b["after"]
     assert a["forced"] == b["forced"] == "ring" and a["other_shape"] == "gather"
     assert a["ms"] == b["ms"]                                     # max over ranks: identical on both
-    assert a["in_call"] == b["in_call"] == a["chosen"]               # the opt-in in-call measurement: same decision
+    # the opt-in in-call measurement: a SECOND, independent measurement — both ranks take the same decision again (which of
+    # three forms a few microseconds apart wins on CPU timings may differ between two measurements; between ranks never)
+    assert a["in_call"] == b["in_call"] and a["in_call"] in ("gather", "gather_ps", "ring")
     if break_gather:
         assert a["in_call_none"] == b["in_call_none"] == [None, None, "gather"]      # every form broken: no raise, the shape rule
-        assert a["chosen"] == "ring" and a["ms"]["gather"] is None and "gather" in a["failed"] and "gather" in b["failed"]
+        assert a["chosen"] == a["in_call"] == "ring" and a["ms"]["gather"] is None and a["ms"]["gather_ps"] is None
+        assert all(f_ in r_["failed"] for f_ in ("gather", "gather_ps") for r_ in (a, b))
     else:
         assert all(v_ is not None and v_ > 0 for v_ in a["ms"].values())
         for kind in ("all_gather", "all_to_all", "neighbour_hop"):
