@@ -59,3 +59,22 @@ def test_schedules_under_torch_compile_at_world_size_gt_1_on_the_hip_kernels(W, 
         sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
         errs = RW.run_world(W, sel, use_hip=True, port=free_port())
         assert not errs, "\n".join(errs)
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_exchange_audit_passes_on_the_hip_path(W, monkeypatch):
+    """config.exchange_check (RFA_EXCHANGE_CHECK=1, round 6) with DEVICE buffers: every K/V and dK/dV buffer a rank receives
+    is checksummed on the GPU against its sender's checksum (utils.audit_verify; the ranks share this GPU, the transfers are
+    host-staged) — all schedules and every zigzag exchange form must pass the audit and still reproduce the golden vectors."""
+    import _ring_worker as RW
+    import make_golden as MG
+    from conftest import free_port
+
+    monkeypatch.setenv("RFA_EXCHANGE_CHECK", "1")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and "sample" not in c]
+    assert names
+    for mode in ("gather", "ring", "gather_ps"):
+        monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
+        sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
+        errs = RW.run_world(W, sel, use_hip=True, port=free_port())
+        assert not errs, "\n".join(errs)

@@ -115,6 +115,21 @@ def test_collective_sequence_survives_rank_local_state(W, form):
     assert len({r["autotune_after_local_record"]["mine_after"][0] for r in res}) == 1      # one winner for the whole group
 
 
+@pytest.mark.parametrize("W", [2, 3])
+def test_exchange_audit_passes_on_every_schedule(W, monkeypatch):
+    """config.exchange_check on (RFA_EXCHANGE_CHECK=1): every schedule of the package — ring, zigzag in its three exchange
+    forms, stripe, both varlen forms, llama3 (all-gather; its reduce-scatter has no single sender and is not audited),
+    zigzag-llama3 — passes the audit and reproduces the golden vectors of the unmodified reference."""
+    monkeypatch.setenv("RFA_EXCHANGE_CHECK", "1")
+    names = [n for n, c in MG.CASES.items() if c["W"] == W and "sample" not in c]
+    assert names
+    for mode in ("gather", "ring", "gather_ps"):
+        monkeypatch.setenv("RFA_ZIGZAG_EXCHANGE", mode)
+        sel = names if mode == "gather" else [n for n in names if MG.CASES[n]["kind"] == "zigzag"]
+        errs = RW.run_world(W, sel, use_hip=False, port=free_port())
+        assert not errs, "\n".join(errs)
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("W", [2, 3])
 def test_exchange_check_names_a_corrupted_receive(W):
