@@ -135,6 +135,10 @@ class OracleBackend:
         return None
 
     # ------------------------------------------------------------------ side kernels
+    def zero_outside(self, shape, dtype, device, lo, hi, slot=0, dim=0):
+        """HipBackend.zero_outside: a buffer whose rows outside [lo, hi) along `dim` are zero (here: a fresh one per call)"""
+        return torch.zeros(shape, dtype=dtype, device=device)
+
     def merge(self, out_acc, lse_acc, block_out, block_lse, *, acc_init=False):
         """lse_acc / block_lse: (B,H,S) views."""
         if acc_init:

@@ -322,6 +322,31 @@ class HipBackend:
             self._ds_capped.pop(key, None)
         return buf
 
+    def zero_outside(self, shape, dtype, device, lo, hi, slot=0, dim=0):
+        """A reusable buffer of `shape` whose rows OUTSIDE [lo, hi) along `dim` are zero — the dK/dV contribution buffer of
+        the llama3 backward, whose rows inside the range the dK/dV kernel overwrites completely on every call (key blocks
+        without a visible query store zeros) and whose rows outside must read as zero in the reduce-scatter.  Rounds 2-5
+        allocated it per backward and zero-filled the outside rows with torch fills (7 us launches on a
+        0.5 ms step); now ONE buffer per (device, stream, shape, slot) is zeroed when it is made and only the rows that LEAVE
+        the range between two calls are zeroed again (a packed batch whose local key slice shrinks).  Safe to reuse: every
+        caller waits for the collective that reads the buffer before it returns."""
+        cuda = device.type == "cuda"
+        key = ("zero", (device.index if device.index is not None else torch.cuda.current_device()) if cuda else -1,
+               torch.cuda.current_stream(device).cuda_stream if cuda else 0, tuple(shape), dtype, slot, dim)
+        ent = self._ds_pool.get(key)
+        if ent is None:
+            buf = torch.zeros(shape, dtype=dtype, device=device)
+            self._ds_pool[key] = [buf, lo, hi]
+            return buf
+        buf, plo, phi = ent
+        if lo > plo:                                   # rows [plo, lo) were inside, now outside
+            buf.narrow(dim, plo, min(lo, phi) - plo).zero_()
+        if hi < phi:
+            start = max(hi, plo)
+            buf.narrow(dim, start, phi - start).zero_()
+        ent[1], ent[2] = lo, hi
+        return buf
+
     def release_scratch(self):
         """drop the reusable dS scratch buffers (they are re-made on demand): up to config.ds_spill_max_bytes per device
         and stream that the pool otherwise holds for the life of the process — call it before a phase that needs the

@@ -19,6 +19,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | kv_keep_bytes             | RFA_ZIGZAG_KV_KEEP_BYTES        | 4 GiB   | ... unless one call's gathered K/V exceed this |
 | kv_keep_total_bytes       | RFA_ZIGZAG_KV_KEEP_TOTAL_BYTES  | 4 GiB   | ... or all live kept buffers of the process together would (L layers x W x (K,V)) |
 | llama3_gather_max_bytes   | RFA_LLAMA3_GATHER_MAX_BYTES     | 1 GiB   | llama3: head groups fused per collective while the gathered K/V stay below |
+| llama3_min_groups         | RFA_LLAMA3_MIN_GROUPS           | 1       | llama3: never fuse the head groups into fewer than this many super-groups.  With ONE super-group (what small models get: the gathered K/V of Qwen3-0.6B's 8 K/V heads at 16384 tokens are 67 MB) nothing overlaps: all-gather, then attention.  With g super-groups the gather of group i+1 and the reduce-scatter of group i-1 run beside the kernels of group i — at most 1/g of the exchange is exposed — for about 7 % more kernel time at g = 2 (two half-size launches).  Whether that pays is a property of the node's xGMI all-gather rate; unmeasured (no multi-GPU box): 2 is the setting to try first on one |
 | bwd_ds_spill              | RFA_BWD_DS_SPILL                | 1       | 5-GEMM backward (dS hand-off) where eligible; 0: always the 7-GEMM form |
 | ds_spill_max_bytes        | RFA_DS_SPILL_MAX_BYTES          | 4.5 GiB | size of the ONE reusable dS scratch per device and stream; larger hand-offs run in head-group chunks |
 | ds_spill_max_frac         | RFA_DS_SPILL_MAX_FRAC           | 0.5     | ... and never more than this fraction of the memory free when it is first taken |
@@ -82,6 +83,7 @@ class Config:
     kv_keep_bytes: int = 4 * _GiB
     kv_keep_total_bytes: int = 4 * _GiB
     llama3_gather_max_bytes: int = 1 * _GiB
+    llama3_min_groups: int = 1
     bwd_ds_spill: bool = True
     ds_spill_max_bytes: int = 9 * _GiB // 2
     ds_spill_max_frac: float = 0.5
@@ -136,6 +138,8 @@ class Config:
             c.dkdv_nsplit = _int("RFA_DKDV_NSPLIT", r)
         if (r := get("RFA_FWD_KV_NSPLIT")) is not None:
             c.fwd_kv_nsplit = _int("RFA_FWD_KV_NSPLIT", r)
+        if (r := get("RFA_LLAMA3_MIN_GROUPS")) is not None:
+            c.llama3_min_groups = _int("RFA_LLAMA3_MIN_GROUPS", r, lo=1)
         if (r := get("RFA_TUNING_LOG")) is not None:
             c.tuning_log = _bool("RFA_TUNING_LOG", r)
         if (r := get("RFA_EXCHANGE_CHECK")) is not None:

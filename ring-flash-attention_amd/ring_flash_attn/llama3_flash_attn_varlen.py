@@ -33,14 +33,16 @@ from ._common import _as_cu, dropout_arg, draw_dropout_seed, packed_pair
 
 def fused_heads_k_stride(nheads_k: int, heads_k_stride: int, total_k: int, world: int, head_dim: int,
                          elt_bytes: int) -> int:
-    """kv heads per super-group: the largest multiple of heads_k_stride that divides nheads_k and keeps the
-    double-buffered gathered K/V below the budget (never smaller than heads_k_stride itself)."""
-    budget = config.get().llama3_gather_max_bytes
+    """kv heads per super-group: the largest multiple of heads_k_stride that divides nheads_k, keeps the
+    double-buffered gathered K/V below the budget and leaves at least config.llama3_min_groups super-groups (so that
+    the exchange of one group can run beside the kernels of another) — never smaller than heads_k_stride itself."""
+    cfg = config.get()
+    budget = cfg.llama3_gather_max_bytes
     per_head = 2 * total_k * world * head_dim * elt_bytes          # K and V of one kv head, all ranks
     best = heads_k_stride
     for m in range(1, nheads_k // heads_k_stride + 1):
         hs = m * heads_k_stride
-        if nheads_k % hs == 0 and 2 * hs * per_head <= budget:
+        if nheads_k % hs == 0 and 2 * hs * per_head <= budget and nheads_k // hs >= cfg.llama3_min_groups:
             best = hs
     return best
 
@@ -243,11 +245,10 @@ def llama3_flash_attn_varlen_backward(
         buf = torch.empty((rows_all,) + tuple(kvp.shape[1:]), dtype=k.dtype, device=k.device)
         comm = Comm(process_group)
         comm.all_gather(buf, kvp)
-        dkvc = torch.empty_like(buf)
-        if lo > 0:
-            dkvc[:lo].zero_()
-        if hi < rows_all:
-            dkvc[hi:].zero_()
+        # this rank's contributions for EVERY rank's rows: the rows outside the local key slice stay zero in a buffer that is
+        # kept and reused (backend.zero_outside: no fill launches per backward); the reduce-scatter below is waited for
+        # before this function returns, so the next backward may write into it again
+        dkvc = be.zero_outside(buf.shape, buf.dtype, buf.device, lo, hi)
         comm.wait()
         be.bwd(dout, q, buf[local_k_slice, 0], buf[local_k_slice, 1], softmax_lse, delta, softmax_scale=softmax_scale,
                causal=causal, dq=dq, dk=dkvc[local_k_slice, 0], dv=dkvc[local_k_slice, 1], deterministic=deterministic,
@@ -262,12 +263,13 @@ def llama3_flash_attn_varlen_backward(
     groups = list(range(0, nheads_k, hs))
     nbuf = min(2, len(groups))
     kv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
-    # this rank's dK/dV contributions for EVERY rank's rows (summed over ranks by the reduce-scatter)
-    dkv_bufs = [torch.empty((2, rows_all, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
+    lo, hi = local_k_slice.start or 0, local_k_slice.stop if local_k_slice.stop is not None else rows_all
+    # this rank's dK/dV contributions for EVERY rank's rows (summed over ranks by the reduce-scatter): two kept buffers whose
+    # rows outside the local key slice stay zero (backend.zero_outside) instead of two fills per head group
+    dkv_bufs = [be.zero_outside((2, rows_all, hs, head_dim), k.dtype, k.device, lo, hi, slot=1 + i, dim=1) for i in range(nbuf)]
     whole = hs == nheads_k and dk.is_contiguous() and dv.is_contiguous()   # then the reduce-scatter lands in dk / dv directly
     if not whole:                                # its output must be contiguous
         rs_out = [torch.empty((2, total_k, hs, head_dim), dtype=k.dtype, device=k.device) for _ in range(nbuf)]
-    lo, hi = local_k_slice.start or 0, local_k_slice.stop if local_k_slice.stop is not None else rows_all
 
     def post_gather(gi):
         g0 = groups[gi]
@@ -294,10 +296,6 @@ def llama3_flash_attn_varlen_backward(
         if gi + 1 < len(groups):
             pending = post_gather(gi + 1)
         dkv = dkv_bufs[gi % 2]                   # (its previous reduce-scatter, group gi-2, was finished at gi-1)
-        if lo > 0:
-            dkv[:, :lo].zero_()
-        if hi < rows_all:
-            dkv[:, hi:].zero_()
         q_slice = slice(g0 * nheads // nheads_k, (g0 + hs) * nheads // nheads_k)
         be.bwd(dout[:, q_slice], q[:, q_slice], kv[0][local_k_slice], kv[1][local_k_slice],
                softmax_lse[q_slice], delta[q_slice], softmax_scale=softmax_scale, causal=causal,

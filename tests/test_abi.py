@@ -498,3 +498,34 @@ def test_tuned_kernels_run_two_waves_per_simd_without_scratch(tmp_path):
     for k, per_dtype in (("fwd_kernel", 3), ("dq_kernel", 2), ("dkdv_kernel", 2)):      # (forward: + the 128-row form of D = 96)
         n96 = [n for n in kinds[k] if "Li96E" in n]
         assert len(n96) == 2 * per_dtype, (k, n96)
+
+
+def test_zero_outside_rezeroes_only_the_rows_that_leave_the_range(built):
+    """backend.zero_outside (round 6): the llama3 backward's dK/dV contribution buffer is kept and reused —
+    its rows outside the local key slice must read as zero in the reduce-scatter, the rows inside are overwritten by the
+    dK/dV kernel on every call.  Zeroed once when made; between calls only the rows that LEAVE the range are zeroed again
+    (host logic: no device needed)."""
+    import torch
+    from ring_flash_attn.backend import HipBackend
+
+    be, dev = HipBackend(), torch.device("cpu")
+    b = be.zero_outside((8, 2), torch.float32, dev, 2, 6)
+    assert b.shape == (8, 2) and not b.any()
+    b[2:6] = 1.0                                             # (the kernel's stores)
+    b2 = be.zero_outside((8, 2), torch.float32, dev, 3, 5)   # the range shrinks on both sides
+    assert b2.data_ptr() == b.data_ptr()
+    assert b2[:, 0].tolist() == [0, 0, 0, 1, 1, 0, 0, 0]
+    b2[3:5] = 2.0
+    b3 = be.zero_outside((8, 2), torch.float32, dev, 1, 7)   # grows: nothing to zero (the kernel overwrites [1, 7))
+    assert b3[:, 0].tolist() == [0, 0, 0, 2, 2, 0, 0, 0]
+    b3[1:7] = 3.0
+    b4 = be.zero_outside((8, 2), torch.float32, dev, 6, 8)   # moves: [1, 6) left the range
+    assert b4[:, 0].tolist() == [0, 0, 0, 0, 0, 0, 3, 0]
+    # another slot / dim is another buffer; dim = 1: (2, rows, ...) layouts
+    c = be.zero_outside((2, 8), torch.float32, dev, 2, 6, slot=1, dim=1)
+    assert c.data_ptr() != b.data_ptr() and not c.any()
+    c[:, 2:6] = 1.0
+    c2 = be.zero_outside((2, 8), torch.float32, dev, 4, 6, slot=1, dim=1)
+    assert c2[0].tolist() == [0, 0, 0, 0, 1, 1, 0, 0]
+    be.release_scratch()
+    assert not be.zero_outside((8, 2), torch.float32, dev, 0, 8).any()

@@ -87,3 +87,24 @@ def test_autotune_records_are_per_group():
         assert tuning.lookup((1, 64, 8, 128), (1, 64, 2, 128), "bf16", 4, b) is None
     finally:
         tuning._TUNED.pop(ka, None)
+
+
+def test_llama3_min_groups_limits_the_head_fusion(monkeypatch):
+    """config.llama3_min_groups (round 6): small models fuse all K/V heads into ONE super-group, which leaves nothing for the
+    all-gather / reduce-scatter to overlap with; the knob keeps at least that many groups (results are unchanged: heads are
+    independent — tests/test_schedules_cpu.py::test_llama3_fused_equals_unfused_four_groups)."""
+    from ring_flash_attn import config
+    from ring_flash_attn.llama3_flash_attn_varlen import fused_heads_k_stride as f
+
+    assert f(8, 1, 2048, 8, 128, 2) == 8                      # Qwen3-0.6B at 2048 tokens per rank: everything fused
+    with config.override(llama3_min_groups=2):
+        assert f(8, 1, 2048, 8, 128, 2) == 4
+    with config.override(llama3_min_groups=4):
+        assert f(8, 1, 2048, 8, 128, 2) == 2 and f(8, 4, 2048, 8, 128, 2) == 4     # (never below heads_k_stride)
+    monkeypatch.setenv("RFA_LLAMA3_MIN_GROUPS", "2")
+    assert config.get().llama3_min_groups == 2
+    import pytest
+
+    with pytest.raises(ValueError, match="RFA_LLAMA3_MIN_GROUPS"):       # (tests/conftest.py re-resolves on every RFA_* change)
+        monkeypatch.setenv("RFA_LLAMA3_MIN_GROUPS", "0")
+    monkeypatch.delenv("RFA_LLAMA3_MIN_GROUPS")
