@@ -421,8 +421,9 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
     if (a->k_half != RFA_HALF_FULL) sk = (sk + 1) / 2;
     if (a->q_half != RFA_HALF_FULL) sq = (sq + 1) / 2;
   }
+  const bool big = a->D > kHeadDim;          // rfa_bigd.hip: 128-key workgroups (one wave per SIMD), 32-row Q/dO tiles; ONE form
   const int G = a->H / a->Hk;
-  const int64_t key[8] = {2, a->B, hk_launch, G, sq, sk, a->causal ? 1 : 0, (a->D == 64 ? 2 : 0) | (only_wide ? 1 : 0)};
+  const int64_t key[8] = {2, a->B, hk_launch, G, sq, sk, a->causal ? 1 : 0, (big ? 4 : 0) | (a->D == 64 ? 2 : 0) | (only_wide ? 1 : 0)};
   const uint64_t h = plan_hash(key, 8);
   int code;
   if (plan_lookup(h, &code)) {
@@ -431,7 +432,8 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
   }
   const int off = sk - sq;
   const int64_t mult = (int64_t)a->B * hk_launch;
-  const int ntq = (sq + 63) / 64;
+  const int trows = big ? 32 : 64;
+  const int ntq = (sq + trows - 1) / trows;
   auto estimate = [&](int keys, int ns) {
     const int nkb = (sk + keys - 1) / keys;
     std::vector<int> sizes;
@@ -439,7 +441,7 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
     for (int kb = 0; kb < nkb; ++kb) {
       int qfirst = a->causal ? kb * keys - off : 0;
       qfirst = qfirst < 0 ? 0 : qfirst;
-      const int nt = ntq - qfirst / 64 > 0 ? ntq - qfirst / 64 : 0;
+      const int nt = ntq - qfirst / trows > 0 ? ntq - qfirst / trows : 0;
       for (int sidx = 0; sidx < ns; ++sidx) {
         const int n = nt > sidx ? (nt - 1 - sidx) / ns + 1 : 0;        // tiles nt-1-sidx, nt-1-sidx-ns, ... (dkdv_kernel)
         for (int64_t m = 0; m < mult; ++m) sizes.push_back(n * G);
@@ -450,10 +452,23 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
     if (mk <= 0) return 0.0;
     double busy = work / (mk * kPlanSlots);
     busy = busy > 1 ? 1 : busy;
-    return mk * (keys == 128 ? 0.7 : 1.0) * (1 + kPlanBusyGain * busy * busy) + (ns > 1 ? 12.0 : 0.0);
+    return mk * (keys == 128 && !big ? 0.7 : 1.0) * (1 + kPlanBusyGain * busy * busy) + (ns > 1 ? 12.0 : 0.0);
   };
   double best = -1;
   int wide = 0, best_ns = 1;
+  if (big) {
+    for (int ns = 1; ns <= 8; ++ns) {
+      if (ns == 5 || ns == 7 || (ns > 1 && ntq / ns < 8)) continue;     // (shares of at least 8 tiles of 32 rows, as rounds 3-5)
+      const double c = estimate(128, ns);
+      if (best < 0 || c < 0.98 * best) {
+        best = c;
+        best_ns = ns;
+      }
+    }
+    plan_store(h, best_ns);
+    *ns_out = best_ns;
+    return 0;
+  }
   if (!only_wide) best = estimate(128, 1);
   for (int ns = 1; ns <= 8; ++ns) {
     if (ns == 5 || ns == 7) continue;
@@ -474,17 +489,11 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
 static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
   DkdvPlan pl{0, 1};
   if (a->D > kHeadDim) {
-    // rfa_bigd.hip: 128-key workgroups that occupy a CU each (one wave per SIMD).  A causal launch is as long as its
-    // heaviest key block, so the tile range of a key block is shared by up to 4 workgroups (fp32 partials, summed by
-    // reduce_kernel) until the launch has about two workgroups per CU, each share with at least 8 tiles of 32 rows.
-    const int64_t sk_ = eff_len(a->Sk, a->k_half), sq_ = eff_len(a->Sq, a->q_half);
-    int64_t kb = (int64_t)a->B * ((sk_ + 127) / 128);
-    if (a->cu_seqlens_k != nullptr && a->total_k > 0) {
-      const int64_t eff = (a->total_k + 127) / 128 + a->B;
-      kb = eff < kb ? eff : kb;
-    }
+    // rfa_bigd.hip: 128-key workgroups that occupy a CU each (one wave per SIMD); the tile range of a key block is shared by
+    // the number of workgroups with the smallest estimated makespan (fp32 partials, summed by reduce_kernel; round 6: the
+    // same estimate as the 128-wide kernels' plan instead of "until about two workgroups per CU")
     int ns = 1;
-    while (ns < 4 && kb * hk_launch * ns < 448 && sq_ / (ns + 1) >= 256) ++ns;
+    (void)bwd_dkdv_cost_plan(a, hk_launch, false, &ns);
     if (a->dkdv_nsplit > 0) ns = a->dkdv_nsplit > 8 ? 8 : a->dkdv_nsplit;
     pl.nsplit = ns;
     return pl;

@@ -925,6 +925,369 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   if constexpr (kDoV) store(std::integral_constant<int, 1>{}, accv);
 }
 
+// =====================================================================================
+// dK + dV in ONE launch (round 6)
+// =====================================================================================
+// The two launches above load every Q/dO tile twice and compute S twice (80 MFMAs per tile and wave for 64 of useful
+// work).  Holding both accumulator sets AND both register B operands (K_w, V_w) overflows the arch-VGPR half of the
+// register file (the kWhich = 2 instance above: 212 bytes of scratch in the tile loop).  This form keeps what must be in
+// registers — dK^T / dV^T (2 x 128 accumulator registers: hipcc places them in the AGPR half) and K_w (64) — and puts the
+// workgroup's 128 V rows into LDS ONCE (64 KiB, the arrangement of rfa_bwd.hip's 128-wide kernel): the dP GEMM reads both of
+// its operands from LDS (16 more ds_read_b128 per tile and wave).  To make room the Q/dO ring shrinks from 4 stages to 2:
+// with 64 MFMAs per tile (>= 2048 cycles) one tile in flight covers a DMA round trip where 32 - 48 did not.  Per tile and
+// wave: 64 MFMAs, 112 LDS reads, 9 DMA pieces, one barrier — against 80 / 112 / 18 / two.
+#ifndef RFA_FU_PIN_SCORES
+#define RFA_FU_PIN_SCORES 0  // 1: K_w named as arch VGPRs at the top of every tile (no scratch, but MORE accumulator-register moves:
+#endif                       // 486 - 494 against 503 - 506 TFLOP/s at D = 192, round 6)
+#ifndef RFA_FU_SCORES_SERIAL
+#define RFA_FU_SCORES_SERIAL 0  // 1: exp phase between the S and the dP chain (one score chain in accumulator registers at a time): same
+#endif                          // accumulator-register traffic in hipcc's allocation, not kept
+#ifndef RFA_FU_AHEAD
+#define RFA_FU_AHEAD 4       // fragments read ahead of their MFMA in the fused kernel's GEMMs
+#endif
+constexpr int kFuStages = 2;
+constexpr int kFuOffDo = kFuStages * kBgQTile;       // dO stages behind the Q stages (32 KiB)
+constexpr int kFuOffV = 2 * kFuOffDo;                // 64 KiB: V rows [128][256] as two [128][128] chunk tiles
+constexpr int kFuVChunk = kBgRows * 256;             // 32 KiB
+constexpr int kFuOffStat = kFuOffV + 2 * kFuVChunk;  // 128 KiB
+constexpr int kFuSmem = kFuOffStat + kFuStages * kBgStatBytes;
+
+// kDrop: dropout instances (the mask hash of 16 scores per lane and tile lives in its own instance: as a run-time branch its
+// registers inflate the pressure of the tile loop of every call)
+template <typename T, int kQ, bool kDrop>
+__global__ __launch_bounds__(kBgThreads) void dkdv_fused_big_kernel(const BwdParams p) {
+  constexpr int kNK = 4 * kQ, kNB = 2 * kQ;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+  if (lds_addr(smem) & 0xffff) __builtin_trap();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+
+  int idx = blockIdx.x;
+  const int G = p.H / p.Hk;
+  const int hk = idx % p.Hk;
+  idx /= p.Hk;
+  const int nsplit = p.nsplit;
+  const int qsplit = idx % nsplit;
+  idx /= nsplit;
+  const int kblk = idx % p.nkblk;
+  const int b = idx / p.nkblk;
+  const int h0 = hk * G;
+
+  const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int kwg0 = kblk * kBgRows;
+  if (kwg0 >= lk) return;
+  const int off = lk - lq;
+  const int kw0 = kwg0 + wave * 32;
+  const int krow = kw0 + l31;
+  const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
+  const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+
+  const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
+  const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
+  const T* qbase0 = (const T*)p.q + qbatch * p.q_st.batch + qs.row0 * p.q_st.row + (int64_t)h0 * p.q_st.head;
+  const T* dobase0 = (const T*)p.dout + qbatch * p.dout_st.batch + qs.row0 * p.dout_st.row + (int64_t)h0 * p.dout_st.head;
+  const float* lsebase0 = p.lse + qbatch * p.lse_batch + (int64_t)h0 * p.lse_head + qs.row0;
+  const float* dltbase0 = p.delta + qbatch * p.delta_batch + (int64_t)h0 * p.delta_head + qs.row0;
+
+  const bool win = p.wl >= 0 || (p.wr >= 0 && !p.causal);
+  const bool hi = win ? p.wr >= 0 : p.causal != 0;
+  const bool lo = win && p.wl >= 0;
+  const int wr = win ? p.wr : 0, wl = win ? p.wl : 0;
+  int qfirst = 0;
+  if (hi) {
+    qfirst = kwg0 - off - wr;
+    if (qfirst < 0) qfirst = 0;
+  }
+  int qlast = lq;
+  if (lo && kwg0 + kBgRows - off + wl < qlast) qlast = kwg0 + kBgRows - off + wl;
+  const int jt0 = qfirst / kBgQ;
+  int jt1 = (qlast + kBgQ - 1) / kBgQ;
+  if (jt1 <= jt0) jt1 = jt0;
+  const int jtop = jt1 - 1 - qsplit;
+  const int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
+
+  // the workgroup's 128 V rows -> LDS (one DMA burst; rows past the end of the sequence read as zeros), this wave's K rows
+  // -> registers (B operand of S = Q K_w^T)
+  {
+    int voff_v[kBgRows / 8];
+    big_dma_offsets<kBgRows>(wave, lane, (int)p.v_st.row, p.D, voff_v);
+    int rows = lk - kwg0;
+    rows = rows < kBgRows ? rows : kBgRows;
+    const dma_rsrc_t rv = make_dma_rsrc(vbase + (int64_t)kwg0 * p.v_st.row, ((rows - 1) * (int)p.v_st.row + p.D) * 2);
+    big_dma_tile<kBgRows>(rv, lds_addr(smem) + kFuOffV, wave, voff_v);
+  }
+  vec8<T> kwr[kNK];
+  {
+    const int kr = krow < lk ? krow : lk - 1;
+    const T* kp = kbase + (int64_t)kr * p.k_st.row;
+#pragma unroll
+    for (int kk = 0; kk < kNK; ++kk) {
+      const int d0 = 16 * kk + 8 * g;
+      kwr[kk] = d0 < p.D ? *(const vec8<T>*)(kp + d0) : zero8<T>();
+    }
+  }
+
+  int voff_q[kBgQ / 8], voff_do[kBgQ / 8];
+  big_dma_offsets<kBgQ>(wave, lane, (int)p.q_st.row, p.D, voff_q);
+  big_dma_offsets<kBgQ>(wave, lane, (int)p.dout_st.row, p.D, voff_do);
+  const int ntile = ntile_q * G;
+  int ld_n = 0, ld_g = 0, ld_j = jtop > 0 ? jtop : 0;
+  struct TileLoad {
+    dma_rsrc_t rq, rdo, rs;
+    int base, sbase;
+  };
+  auto prep_tile = [&]() {
+    const bool valid = ld_n < ntile;
+    const int j = valid ? ld_j : 0;
+    const int stage = ld_n & (kFuStages - 1);
+    const T* qbase = qbase0 + (int64_t)ld_g * p.q_st.head;
+    const T* dobase = dobase0 + (int64_t)ld_g * p.dout_st.head;
+    const float* statbase = (wave ? dltbase0 + (int64_t)ld_g * p.delta_head : lsebase0 + (int64_t)ld_g * p.lse_head) + j * kBgQ;
+    ++ld_n;
+    if (++ld_g >= G) {
+      ld_g = 0;
+      ld_j -= nsplit;
+    }
+    int rows = lq - j * kBgQ;
+    rows = rows < kBgQ ? rows : kBgQ;
+    rows = valid && rows > 0 ? rows : 0;
+    const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
+    const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
+    TileLoad t;
+    t.rq = make_dma_rsrc(qbase + (int64_t)j * kBgQ * p.q_st.row, nq);
+    t.rdo = make_dma_rsrc(dobase + (int64_t)j * kBgQ * p.dout_st.row, ndo);
+    t.rs = make_dma_rsrc(statbase, rows * 4);
+    t.base = lds_addr(smem) + stage * kBgQTile;
+    t.sbase = lds_addr(smem) + kFuOffStat + stage * kBgStatBytes + wave * 256;
+    return t;
+  };
+  constexpr int kPieces = 2 * (kBgQ / 8) + 1;
+  auto issue_piece = [&](const TileLoad& t, int i) {
+    if (i < kBgQ / 8) big_dma_piece<kBgQ>(t.rq, t.base, wave, voff_q, i);
+    else if (i < 2 * (kBgQ / 8)) big_dma_piece<kBgQ>(t.rdo, t.base + kFuOffDo, wave, voff_do, i - kBgQ / 8);
+    else if (wave < 2) dma_load32(t.rs, t.sbase, lane * 4);
+  };
+
+  const int aq0 = lds_addr(smem) + tile_off(l31, g);
+  const int av = lds_addr(smem) + kFuOffV + 32 * wave * 256 + tile_off(l31, g);      // this wave's V rows (B operand of dP)
+  int tq0[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) tq0[hh] = lds_addr(smem) + tr_off_d<128>(lane, 0, 8 * hh + 4 * g);
+  const int sa0 = lds_addr(smem) + kFuOffStat + 4 * g * 4;
+
+  constexpr bool drop = kDrop;
+  const uint32_t drop_j = drop ? p.k_pos0 + (uint32_t)(p.cu_k ? ks.row0 : 0) + (uint32_t)krow : 0u;
+  const uint32_t drop_i0 = drop ? p.q_pos0 + (uint32_t)(p.cu_q ? qs.row0 : 0) : 0u;
+  const float c = p.scale * kLog2e;
+  f32x16 acck[kNB], accv[kNB];
+#pragma unroll
+  for (int i = 0; i < kNB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acck[i][r] = 0.f;
+      accv[i][r] = 0.f;
+    }
+
+  const bool spill = p.ds != nullptr;
+  const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
+  const int ds_nkb = ds_blocks(p.Sk, p.k_half);
+  const int64_t ds_head_bytes = spill ? p.ds_head_blocks * kDsBlockBytes : 0;
+  const char* ds_b = spill ? (const char*)p.ds + ds_base_blocks(p, b) * kDsBlockBytes : nullptr;
+  const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kBgRows / 32) + wave);
+
+  {
+    const TileLoad t0 = prep_tile();
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) issue_piece(t0, i);
+  }
+  wait_all_vmem();                                     // V rows, K_w, tile 0
+  __syncthreads();
+
+  int j = jtop, cg = 0;
+  for (int f = 0; f < ntile; ++f) {
+    const TileLoad nxt = prep_tile();                  // tile f + 1 goes into the other stage
+    const int so = (f & (kFuStages - 1)) * kBgQTile;
+    const int aq = aq0 + so, tq[2] = {tq0[0] + so, tq0[1] + so};
+    const int sa = sa0 + (f & (kFuStages - 1)) * kBgStatBytes;
+    const int qs0 = j * kBgQ;
+    const bool active = (kw0 < lk) && (qs0 < lq) && !(hi && qs0 + 31 + off + wr < kw0) && !(lo && qs0 + off - wl > kw0 + 31);
+    if (active) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#if !RFA_FU_SCORES_SERIAL
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * jj + e] = -dl[e];
+      }
+#endif
+#if RFA_FU_PIN_SCORES
+      // In a kernel that uses AGPRs every MFMA accumulates in AGPRs: dK^T, dV^T (192 at kQ = 3) and the two score chains (32).
+      // Left alone, hipcc ALSO parks K_w there (48: an MFMA-only operand), over-subscribes the 256 AGPRs and pays for it with
+      // 209 v_accvgpr_write + 50 v_accvgpr_read per tile.  An empty asm that names K_w as arch VGPRs keeps it where it is.
+#pragma unroll
+      for (int kk = 0; kk < kNK; ++kk) asm volatile("" : "+v"(kwr[kk]));
+#endif
+      // S = Q K_w^T: the next tile's DMA pieces in the shadows of its first MFMAs
+      big_gemm<T, kNK, 1>(
+          [&](int kk) { return lds_read128<T>(lds_ptr(aq ^ ((kk & 7) << 5)) + (kk >> 3) * kBgQChunk); },
+          [&](int kk, vec8<T> a) { s = mfma(a, kwr[kk], s); },
+          [&](int i) {
+            if (i < kPieces) issue_piece(nxt, i);
+          });
+#if RFA_FU_SCORES_SERIAL
+      // P first (the S chain's accumulator registers are dead once P sits in arch VGPRs), THEN the dP chain: one score chain
+      // in accumulator registers at a time
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 ls = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * ls[e]));
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * jj + e] = -dl[e];
+      }
+#endif
+      // dP - delta = dO V_w^T: both operands from LDS, read kAhead MFMAs ahead
+      {
+        constexpr int kAhead = RFA_FU_AHEAD < kNK ? RFA_FU_AHEAD : kNK;
+        vec8<T> a[kNK], w[kNK];
+        auto fa = [&](int kk) { return lds_read128<T>(lds_ptr(aq ^ ((kk & 7) << 5)) + (kk >> 3) * kBgQChunk + kFuOffDo); };
+        auto fw = [&](int kk) { return lds_read128<T>(lds_ptr(av ^ ((kk & 7) << 5)) + (kk >> 3) * kFuVChunk); };
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) { a[i] = fa(i); w[i] = fw(i); }
+#pragma unroll
+        for (int i = 0; i < kNK; ++i) {
+          if (i + kAhead < kNK) { a[i + kAhead] = fa(i + kAhead); w[i + kAhead] = fw(i + kAhead); }
+          dp = mfma(a[i], w[i], dp);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAhead, 0);
+#pragma unroll
+        for (int i = 0; i < kNK - kAhead; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
+      }
+#if !RFA_FU_SCORES_SERIAL
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 ls = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 8 * jj * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[4 * jj + e] = fast_exp2(__builtin_fmaf(s[4 * jj + e], c, -kLog2e * ls[e]));
+      }
+#endif
+      const bool need_mask = (qs0 + 32 > lq) || (hi && qs0 + off + wr < kw0 + 31) || (lo && qs0 + 31 + off - wl > kw0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // (bitwise, not short-circuit: with && / || hipcc builds a branch per element — 34 branches per masked tile)
+          const int q = qs0 + crow(r, g);
+          const bool ok = (q < lq) & (!hi | (krow <= q + off + wr)) & (!lo | (krow >= q + off - wl));
+          s[r] = ok ? s[r] : 0.f;
+        }
+      }
+      // pbv = the (dropped, rescaled) P for the dV GEMM; s becomes dS = P (dP - delta) for the dK GEMM
+      vec8<T> pbv[2];
+      if (drop) {
+        const uint32_t hkey = drop_head_key(p.drop_seed, p.cu_q ? 0u : (uint32_t)b, p.head0 + (uint32_t)(h0 + cg));
+        f32x16 pv;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 dl = *(__attribute__((address_space(3))) f32x4*)(lds_ptr(sa) + 256 + 8 * jj * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * jj + e;
+            const uint32_t w = drop_word(hkey, drop_i0 + (uint32_t)(qs0 + crow(r, g)), drop_j >> 2);
+            const bool keep = drop_keep(w, (int)(drop_j & 3u), p.drop_keep);
+            pv[r] = keep ? s[r] * p.drop_scale : 0.f;
+            const float dpd = keep ? (dp[r] + dl[e]) * p.drop_scale - dl[e] : -dl[e];
+            s[r] = dpd * s[r];
+          }
+        }
+        pbv[0] = pack8<T>(pv, 0);
+        pbv[1] = pack8<T>(pv, 8);
+      } else {
+        pbv[0] = pack8<T>(s, 0);
+        pbv[1] = pack8<T>(s, 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] *= dp[r];
+      }
+      const vec8<T> pbk[2] = {pack8<T>(s, 0), pack8<T>(s, 8)};
+      if (spill) {
+        const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes + (ds_rowpart(p, j, (qs.row0 >> 5) + b, ds_nkb) + ds_kb) * kDsBlockBytes;
+        const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pbk[0]), rb, ds_lane, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pbk[1]), rb, ds_lane + 128, 0, 2);
+      }
+      // dV^T += dO^T P, dK^T += Q^T dS: A operands by transpose reads of the dO / Q tile
+      big_gemm<T, 2 * kNB, 2>(
+          [&](int i) {
+            const int dblk = i % kNB, imm = 16 * (i / kNB) * 256 + (dblk >> 2) * kBgQChunk + kFuOffDo;
+            return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
+          },
+          [&](int i, vec8<T> a) { accv[i % kNB] = mfma(a, pbv[i / kNB], accv[i % kNB]); });
+      big_gemm<T, 2 * kNB, 2>(
+          [&](int i) {
+            const int dblk = i % kNB, imm = 16 * (i / kNB) * 256 + (dblk >> 2) * kBgQChunk;
+            return concat<T>(lds_read_tr<T>(lds_ptr(tq[0] ^ ((dblk & 3) << 6)) + imm), lds_read_tr<T>(lds_ptr(tq[1] ^ ((dblk & 3) << 6)) + imm));
+          },
+          [&](int i, vec8<T> a) { acck[i % kNB] = mfma(a, pbk[i / kNB], acck[i % kNB]); });
+    } else {
+#pragma unroll
+      for (int i = 0; i < kPieces; ++i) issue_piece(nxt, i);
+    }
+    // tile f + 1 must have landed; this tile's two dS spill stores (the youngest operations) may stay in flight
+    if (spill && active) wait_vmem64<2>();
+    else wait_all_vmem();
+    if (++cg >= G) {
+      cg = 0;
+      j -= nsplit;
+    }
+    __syncthreads();
+  }
+  wait_all_vmem();
+
+  if (krow >= lk) return;
+  const int64_t orow = ks.row0 + krow;
+  auto store = [&](auto whichc, const f32x16 (&acc)[kNB]) {
+    constexpr int which = decltype(whichc)::value;     // 0 = dK, 1 = dV
+    const float sc_ = which ? 1.f : p.scale;
+    const Strides st = which ? p.dv_st : p.dk_st;
+    const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head + (int64_t)qsplit * p.kv_split_stride;
+    if (p.kv_f32) {
+      float* ob = (float*)(which ? p.dv : p.dk) + eoff;
+#pragma unroll
+      for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d0 = 32 * dblk + 8 * jj + 4 * g;
+          if (d0 < p.D) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = acc[dblk][4 * jj + e] * sc_;
+            *(f32x4*)(ob + d0) = x;
+          }
+        }
+    } else {
+      store_rows16<T, false, kNB>((T*)(which ? p.dv : p.dk) + eoff, acc, sc_, g, p.D, true);
+    }
+  };
+  store(std::integral_constant<int, 0>{}, acck);
+  store(std::integral_constant<int, 1>{}, accv);
+}
+
 // ------------------------------------------------------------------------------------
 static inline int big_len(int S, int half) { return half ? (S + 1) / 2 : S; }
 
@@ -964,9 +1327,22 @@ int launch_bwd_dq_big(const BwdParams& p0, int dtype, hipStream_t stream) {
   return dtype == 0 ? launch_dq_big_t<bf16_t, 4>(p, n, stream) : launch_dq_big_t<f16_t, 4>(p, n, stream);
 }
 
+#ifndef RFA_BG_FUSED2
+#define RFA_BG_FUSED2 1      // round 6: dK and dV in one launch with the V rows in LDS (dkdv_fused_big_kernel); 0: one launch per tensor
+#endif
 template <typename T, int kQ>
 static int launch_dkdv_big_t(const BwdParams& p, int64_t n, hipStream_t stream) {
-  static std::atomic<unsigned long long> done[2];
+  static std::atomic<unsigned long long> done[3];
+#if RFA_BG_FUSED2
+  // head dims <= 192 (kQ = 3: 2 x 96 accumulator registers + 48 of K_w): one launch.  At kQ = 4 the two accumulator sets fill
+  // the AGPR half exactly, hipcc has no register left to park arch values in and the tile loop goes to scratch (55 scratch
+  // operations per tile: measured 293 against 450 TFLOP/s) — D > 192 keeps one launch per tensor.
+  if constexpr (kQ == 3) {
+    if (p.drop_keep < 256) return launch_big(dkdv_fused_big_kernel<T, kQ, true>, p, n, kFuSmem, done[2], stream);
+    static std::atomic<unsigned long long> done_plain{0};
+    return launch_big(dkdv_fused_big_kernel<T, kQ, false>, p, n, kFuSmem, done_plain, stream);
+  }
+#endif
 #if RFA_BG_FUSED_KV
   if constexpr (kQ == 3) return launch_big(dkdv_big_kernel<T, 2, kQ>, p, n, kBgKvSmem, done[0], stream);
 #endif

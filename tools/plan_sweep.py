@@ -86,6 +86,11 @@ def bwd_points(quick):
         pts.append(("llama3 Sq2048 Sk8192 H16/8", 1, 2048, 8192, 16, 8, True))
         pts.append(("llama3 Sq2048 Sk16384 H16/8", 1, 2048, 16384, 16, 8, True))
         pts.append(("llama3 Sq2048 Sk16384 H2/1", 1, 2048, 16384, 2, 1, True))
+        # wide head dims (rfa_bigd.hip: one form, the share count is the plan)
+        pts.append(("D256 S8192 H16/4", 1, 8192, 8192, 16, 4, True, 256))
+        pts.append(("D192 S8192 H20/5", 1, 8192, 8192, 20, 5, True, 192))
+        pts.append(("D256 S4096 B2 H8/8", 2, 4096, 4096, 8, 8, True, 256))
+        pts.append(("D256 S2048 H16/4", 1, 2048, 2048, 16, 4, True, 256))
     return pts
 
 
@@ -126,7 +131,9 @@ def sweep(quick=False, log=print, dump=None):
     log("")
     log("| backward shape | chosen ms | best forced ms | best plan | chosen / best |")
     log("|---|---|---|---|---|")
-    for label, B, S, Sk, H, Hk, causal in bwd_points(quick):
+    for pt in bwd_points(quick):
+        label, B, S, Sk, H, Hk, causal = pt[:7]
+        D = pt[7] if len(pt) > 7 else 128
         q = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16)
         k = torch.randn(B, Sk, Hk, D, device=dev, dtype=torch.bfloat16)
         v = torch.randn(B, Sk, Hk, D, device=dev, dtype=torch.bfloat16)
@@ -143,15 +150,16 @@ def sweep(quick=False, log=print, dump=None):
         iters = 15
         chosen = _time(run, iters)
         forced = {}
-        with config.override(dkdv_wide=0):
-            forced["128-key"] = _time(run, iters)
+        if D <= 128:
+            with config.override(dkdv_wide=0):
+                forced["128-key"] = _time(run, iters)
         for ns in (1, 2) + ((3, 4, 6, 8) if S >= 1024 else ()):
             with config.override(dkdv_wide=1, dkdv_nsplit=ns):
-                forced[f"256-key ns{ns}"] = _time(run, iters)
+                forced[f"{'256' if D <= 128 else '128'}-key ns{ns}"] = _time(run, iters)
         chosen = min(chosen, _time(run, iters))
         bname = min(forced, key=forced.get)
         if dump is not None:
-            dump.append(dict(dir="bwd", label=label, B=B, S=S, Sk=Sk, H=H, Hk=Hk, causal=causal, chosen=chosen, forced=forced))
+            dump.append(dict(dir="bwd", label=label, B=B, S=S, Sk=Sk, H=H, Hk=Hk, D=D, causal=causal, chosen=chosen, forced=forced))
         rows.append(("bwd", label, chosen, forced[bname], bname))
         log(f"| {label} | {chosen:.4f} | {forced[bname]:.4f} | {bname} | {chosen / forced[bname]:.3f} |")
     return rows
