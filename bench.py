@@ -155,7 +155,7 @@ def committed_traffic(kernel, hk):
     return sect[kernel], f"profiles/{best} (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes, same binary)"
 
 
-# Round 5 (profiles/r05_power_probe.json): the board sits at its 1400 W cap during the backward and the whole step, and a
+# Round 5 (profiles/history/r05_power_probe.json): the board sits at its 1400 W cap during the backward and the whole step, and a
 # register-only MFMA loop sustains 2.47 PFLOP/s on zero operands but 1.82-1.90 PFLOP/s on random ones — the rate the chip can
 # pay for depends on the data.  `roofline.peak` stays the datasheet's 2.5 PFLOP/s (MI355X_MICROARCH.md); the line additionally
 # quotes the fraction of the MEASURED random-operand rate.  Round 6 (profiles/r06_power_limiters.md): the
@@ -576,7 +576,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: a 0.4 s timed region at N = 1)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: a 0.6 s timed region at N = 1 — long "
+                                                             "enough for the board-power reading, a ~1 s moving average, to be valid)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kv-heads", type=int, default=8, help="8 = the reference benchmark's GQA; 32 = MHA")
     ap.add_argument("--workload", default="zigzag", choices=["zigzag", "ring", "stripe", "ring_varlen", "zigzag_varlen", "llama3"],

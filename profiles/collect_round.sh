@@ -30,6 +30,12 @@ mkdir -p build/tools
 timeout 400 python tools/power_limiters.py --seconds 3 --json $O/${TAG}_power_limiters.json > $O/${TAG}_power_limiters_table.md 2>/dev/null
 timeout 900 python tools/plan_sweep.py > $O/${TAG}_plan_sweep_after.md 2>/dev/null
 timeout 200 python tools/agreement_stall.py > $O/${TAG}_agreement_stall.txt 2>&1
+# wide head dims: the one-launch dK + dV form (head dims <= 192) against one launch per tensor (-DRFA_BG_FUSED2=0) and its variants,
+# when tools/ab_variants.py built them into build/variants/
+{ for v in base nofuse serial1 base nofuse serial1; do
+    if [ $v = base ]; then unset RFA_LIB_PATH; elif [ -f build/variants/$v/librfa_hip.so ]; then export RFA_LIB_PATH=build/variants/$v/librfa_hip.so; else continue; fi
+    echo "== $v"; timeout 200 python tools/shape_sweep.py 1,8192,20,5,192,1 1,8192,16,4,160,1 1,8192,20,5,192,0 1,8192,16,4,256,1 2>/dev/null | grep "^| [0-9]"
+  done; unset RFA_LIB_PATH; } > $O/${TAG}_wide_head_dims.md 2>&1
 ( timeout 300 ./tests/native/selftest ) > $O/${TAG}_native_selftest.txt 2>&1
 ( timeout 300 python __graft_entry__.py smoke ) > $O/${TAG}_smoke.txt 2>&1
 ( time timeout 1500 python -m pytest tests -m gpu -x -q --durations=25 ) > $O/${TAG}_pytest_gpu.log 2>&1
