@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define RFA_ABI_VERSION 5
+#define RFA_ABI_VERSION 6
 
 typedef enum {
   RFA_OK = 0,
@@ -210,6 +210,12 @@ typedef struct {
    * REDUCE phase of one backward — and rfa_bwd_workspace_bytes() — can never disagree).
    *   dkdv_form   RFA_DKDV_AUTO: chosen from the shapes; RFA_DKDV_128: a workgroup owns 128 keys;
    *               RFA_DKDV_256: 256 keys (head dim 128 without a window only, otherwise ignored)
+   *               RFA_DKDV_BAL (ABI 6): 256 keys in the balanced causal schedule — every workgroup of a dense causal
+   *               self-attention block (Sq == Sk, a multiple of 512 rows, head dim 128, single-phase call that writes
+   *               dk / dv or overwrites dk_acc / dv_acc) does the same amount of work, key blocks of the lower half are
+   *               shared by two workgroups that add their partials between themselves: no reduction pass.  Where the
+   *               call is not eligible the field is read as RFA_DKDV_AUTO.  RFA_DKDV_256 with dkdv_nsplit > 0 names the
+   *               shared-range plan instead.
    *   dkdv_nsplit 0: chosen from the shapes; 1..8: workgroups sharing the query range of a key block
    *               (256-key form only)
    * A zero-initialised struct means "auto".  rfa_bwd_plan() reports what a call will run. */
@@ -239,7 +245,7 @@ typedef struct {
   int64_t total_q;
 } rfa_bwd_args;
 
-enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2 };
+enum { RFA_DKDV_AUTO = 0, RFA_DKDV_128 = 1, RFA_DKDV_256 = 2, RFA_DKDV_BAL = 3 };
 
 enum {
   RFA_BWD_ALL = 0,
@@ -286,7 +292,7 @@ int rfa_fwd(const rfa_fwd_args *args, void *stream);
 int64_t rfa_fwd_workspace_bytes(const rfa_fwd_args *args, int32_t *nsplit);
 int rfa_bwd_preprocess(const rfa_bwd_preprocess_args *args, void *stream);
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args *args);
-/* the launch plan of a call: *form = RFA_DKDV_128 / RFA_DKDV_256, *nsplit >= 1, *five_gemm = 1 when the call
+/* the launch plan of a call: *form = RFA_DKDV_128 / RFA_DKDV_256 / RFA_DKDV_BAL, *nsplit >= 1, *five_gemm = 1 when the call
  * (with its ds_scratch) runs the dS-spill form.  Pure function of the arguments. */
 int rfa_bwd_plan(const rfa_bwd_args *args, int32_t *form, int32_t *nsplit, int32_t *five_gemm);
 /* bytes of ds_scratch the whole hand-off of the call uses — dense: B*H*ceil(Sq/32)*ceil(Sk/32)*2048 (dense causal: the

@@ -400,7 +400,7 @@ static bool bwd_kv_direct(const rfa_bwd_args* a) {
 // range of a key block is shared by up to 4 workgroups until the launch has about two workgroups per CU (a causal
 // launch needs that many for its heavy-first order to balance), each with at least 8 tiles.  Launches that stay
 // small even so run the 128-key form (twice the workgroups).
-struct DkdvPlan { int wide, nsplit; };
+struct DkdvPlan { int wide, nsplit, bal; };     // bal: the balanced causal schedule of the 256-key form (dkdv_kernel kBal)
 struct DsChunks { int nchunks, hc, gc; int64_t chunk_bytes; };     // hc K/V heads x gc query heads per K/V head per chunk
 static DsChunks bwd_ds_chunking(const rfa_bwd_args* a);
 // The dK/dV plan by estimated makespan (see "launch plans" above).  Jobs: one workgroup per (batch, K/V head, key block
@@ -411,7 +411,7 @@ static DsChunks bwd_ds_chunking(const rfa_bwd_args* a);
 // pass: 12 tile-times.  Returns wide (0 / 1) and the share count; only_wide: the best share count of the 256-key form.
 // Packed (cu_seqlens) input: the sequences' lengths live on the device — the estimate takes B sequences of the mean
 // length total / B (bounded by max_seqlen), which is what the old rule's "about total_k / 256 key blocks" did.
-static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wide, int* ns_out) {
+static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wide, int* ns_out, int* bal_out = nullptr) {
   int sk = eff_len(a->Sk, a->k_half), sq = eff_len(a->Sq, a->q_half);
   if (a->cu_seqlens_k != nullptr && a->total_k > 0 && a->B > 0) {
     const int64_t mean_k = (a->total_k + a->B - 1) / a->B;
@@ -428,8 +428,10 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
   int code;
   if (plan_lookup(h, &code)) {
     *ns_out = code & 15;
-    return code >> 4;
+    if (bal_out) *bal_out = (code >> 5) & 1;
+    return (code >> 4) & 1;
   }
+  if (bal_out) *bal_out = 0;
   const int off = sk - sq;
   const int64_t mult = (int64_t)a->B * hk_launch;
   const int trows = big ? 32 : 64;
@@ -480,14 +482,38 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
       best_ns = ns;
     }
   }
-  plan_store(h, (wide << 4) | best_ns);
+  // the balanced causal schedule, where the SHAPE allows it (the caller adds the call-level conditions: bwd_bal_eligible):
+  // B * Hk * nkb equal workgroups of (T/2 + 2) G tile-times; half of them cross one key-block seam (a second prologue /
+  // epilogue) and every pair exchanges one partial: 18 tile-times of overhead on average instead of 12, no second pass
+  int bal = 0;
+  if (!only_wide && a->D == kHeadDim && a->causal && sq == sk && sk >= 512 && sk % 512 == 0) {
+    const int nkb = sk / 256;
+    std::vector<int> sizes((size_t)(mult * nkb), (2 * nkb + 2) * G);
+    bal = plan_cost(sizes, 18.0, 0.0) < 0.98 * best ? 1 : 0;
+  }
+  plan_store(h, (bal << 5) | (wide << 4) | best_ns);
   *ns_out = best_ns;
+  if (bal_out) *bal_out = bal;
   return wide;
 }
 
+// The balanced causal schedule (rfa_bwd.hip: dkdv_kernel kBal): every workgroup of a dense causal self-attention block
+// does the same T/2 + 2 tiles' worth of work, only the lower half of the key blocks is shared (by exactly two workgroups
+// that add their partials between themselves): no nsplit fp32 partials per key, no reduce_kernel pass.  Needs the whole
+// call in one launch that writes the final dK/dV (single phase, plain outputs or overwritten accumulators, all heads
+// at once) and a sequence of whole PAIRS of 256-key blocks.
+static bool bwd_bal_eligible(const rfa_bwd_args* a, bool whole_call) {
+  if (a->D != kHeadDim || !a->causal || a->cu_seqlens_q != nullptr || a->dropout_p > 0.f) return false;
+  if (a->window && (a->window_left >= 0 || a->window_right >= 0)) return false;
+  const int lq = eff_len(a->Sq, a->q_half), lk = eff_len(a->Sk, a->k_half);
+  if (lq != lk || lk < 512 || (lk % 512) != 0) return false;
+  if (!bwd_single_phase(a) || (a->phases & (RFA_BWD_SKIP_DKDV | RFA_BWD_SKIP_DQ))) return false;
+  if (a->dk_acc != nullptr && !bwd_kv_direct(a)) return false;
+  return whole_call;                           // (not a head-group chunk of a chunked dS hand-off)
+}
 // hk_launch: K/V heads of ONE dK/dV launch (= Hk, or the K/V heads of a chunk of a chunked dS hand-off)
-static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
-  DkdvPlan pl{0, 1};
+static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch, bool whole_call) {
+  DkdvPlan pl{0, 1, 0};
   if (a->D > kHeadDim) {
     // rfa_bigd.hip: 128-key workgroups that occupy a CU each (one wave per SIMD); the tile range of a key block is shared by
     // the number of workgroups with the smallest estimated makespan (fp32 partials, summed by reduce_kernel; round 6: the
@@ -501,6 +527,10 @@ static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if (a->dkdv_form == RFA_DKDV_128 || (a->D != kHeadDim && a->D != 64) || win || a->dropout_p > 0.f) return pl;
   // a plan asked for by name (tuning, tests; the REDUCE half of a two-phase call repeats its COMPUTE half's plan)
+  if (a->dkdv_form == RFA_DKDV_BAL && bwd_bal_eligible(a, whole_call)) {
+    pl.wide = pl.bal = 1;
+    return pl;
+  }
   if (a->dkdv_form == RFA_DKDV_256 || a->dkdv_nsplit > 0) {
     pl.wide = 1;
     if (a->dkdv_nsplit > 0) {
@@ -514,17 +544,22 @@ static DkdvPlan bwd_dkdv_plan_for(const rfa_bwd_args* a, int hk_launch) {
     }
     return pl;
   }
-  int ns = 1;
-  pl.wide = bwd_dkdv_cost_plan(a, hk_launch, false, &ns);
+  int ns = 1, bal = 0;
+  pl.wide = bwd_dkdv_cost_plan(a, hk_launch, false, &ns, &bal);
   pl.nsplit = pl.wide ? ns : 1;
+  if (bal && bwd_bal_eligible(a, whole_call)) {
+    pl.wide = pl.bal = 1;
+    pl.nsplit = 1;
+  }
   return pl;
 }
 static DkdvPlan bwd_dkdv_plan(const rfa_bwd_args* a) {
   const DsChunks ch = bwd_ds_chunking(a);
-  return bwd_dkdv_plan_for(a, ch.nchunks > 1 ? ch.hc : a->Hk);
+  return bwd_dkdv_plan_for(a, ch.nchunks > 1 ? ch.hc : a->Hk, ch.nchunks <= 1);
 }
 static bool bwd_needs_ws(const rfa_bwd_args* a) {
   if (!bwd_single_phase(a)) return true;
+  if (bwd_dkdv_plan(a).bal) return true;
   if (bwd_dkdv_plan(a).nsplit > 1) return true;
   if (bwd_ds_chunking(a).gc < a->H / a->Hk) return true;      // query-head fractions of a K/V head accumulate in fp32 partials
   return a->dk_acc != nullptr && !bwd_kv_direct(a);
@@ -617,14 +652,22 @@ int rfa_bwd_ds_chunks(const rfa_bwd_args* a, int32_t* nchunks, int32_t* kv_heads
 int rfa_bwd_plan(const rfa_bwd_args* a, int32_t* form, int32_t* nsplit, int32_t* five_gemm) {
   if (!a) return RFA_ERR_NULL;
   const DkdvPlan pl = bwd_dkdv_plan(a);
-  if (form) *form = pl.wide ? RFA_DKDV_256 : RFA_DKDV_128;
+  if (form) *form = pl.bal ? RFA_DKDV_BAL : pl.wide ? RFA_DKDV_256 : RFA_DKDV_128;
   if (nsplit) *nsplit = pl.nsplit;
   if (five_gemm) *five_gemm = bwd_ds_chunking(a).nchunks > 0 ? 1 : 0;
   return RFA_OK;
 }
 
+static int64_t bal_flag_bytes(int64_t pairs) { return (pairs * 4 + 255) / 256 * 256; }
+
 int64_t rfa_bwd_workspace_bytes(const rfa_bwd_args* a) {
   if (!a || !bwd_needs_ws(a)) return 0;
+  // balanced schedule: one fp32 pair slot (dK + dV accumulators of 256 keys) per key block of the lower half of every
+  // (batch, K/V head) + one flag word per pair (rounded up to 256 bytes, in front of the slots)
+  if (bwd_dkdv_plan(a).bal) {
+    const int64_t pairs = (int64_t)a->B * a->Hk * (eff_len(a->Sk, a->k_half) / 512);
+    return bal_flag_bytes(pairs) + pairs * 2 * 256 * (int64_t)a->D * 4;
+  }
   // unsplit: one io-dtype partial per element; split launches: nsplit fp32 partials
   const int ns = bwd_dkdv_plan(a).nsplit;
   const bool f32 = ns > 1 || bwd_ds_chunking(a).gc < a->H / a->Hk;
@@ -642,7 +685,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
   if ((a->dk_acc == nullptr) != (a->dv_acc == nullptr)) return RFA_ERR_ARGS;
   if (!a->dk_acc && (!a->dk || !a->dv)) return RFA_ERR_NULL;
   if ((a->cu_seqlens_q == nullptr) != (a->cu_seqlens_k == nullptr)) return RFA_ERR_ARGS;
-  if (a->dkdv_form < RFA_DKDV_AUTO || a->dkdv_form > RFA_DKDV_256 || a->dkdv_nsplit < 0) return RFA_ERR_ARGS;
+  if (a->dkdv_form < RFA_DKDV_AUTO || a->dkdv_form > RFA_DKDV_BAL || a->dkdv_nsplit < 0) return RFA_ERR_ARGS;
   if (!drop_args_ok(a->dropout_p, a->window, a->window_left, a->window_right, a->causal)) return RFA_ERR_ARGS;
   const bool ws = bwd_needs_ws(a);
   if (ws && !a->workspace) return RFA_ERR_NULL;
@@ -687,7 +730,22 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
 
   Strides ws_st{};
   const bool part_f32 = plan.nsplit > 1 || frac;
-  if (bwd_kv_direct(a) && !part_f32) {
+  if (plan.bal) {
+    // balanced schedule: the kernel writes the FINAL dK / dV itself (io dtype, or the overwritten fp32 accumulators);
+    // the workspace holds the pair flags and the pair slots
+    const int64_t pairs = (int64_t)a->B * a->Hk * (p.nkblk / 2);
+    p.bal = 1;
+    p.pair_flags = (unsigned*)a->workspace;
+    p.pair_ws = (char*)a->workspace + bal_flag_bytes(pairs);
+    if (a->dk_acc) {
+      p.dk = a->dk_acc; p.dv = a->dv_acc;
+      p.dk_st = cv(a->dk_acc_st); p.dv_st = cv(a->dv_acc_st);
+      p.kv_f32 = 1;
+    } else {
+      p.dk = a->dk; p.dv = a->dv;
+      p.dk_st = cv(a->dk_st); p.dv_st = cv(a->dv_st);
+    }
+  } else if (bwd_kv_direct(a) && !part_f32) {
     p.dk = a->dk_acc; p.dv = a->dv_acc;
     p.dk_st = cv(a->dk_acc_st); p.dv_st = cv(a->dv_acc_st);
     p.kv_f32 = 1;
@@ -771,7 +829,7 @@ int rfa_bwd(const rfa_bwd_args* a, void* stream) {
     mark(1);
     mark(2);
   }
-  if (ws && do_reduce) {
+  if (ws && do_reduce && !plan.bal) {
     // dK and dV in one launch (grid z)
     ReduceParams r{};
     r.src = p.dk; r.src2 = p.dv;

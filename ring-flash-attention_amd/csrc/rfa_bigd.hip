@@ -137,8 +137,9 @@ __global__ __launch_bounds__(kBgThreads) void fwd_big_kernel(const FwdParams p) 
   idx /= p.Hk;
   const int gq = idx % G;
   idx /= G;
-  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
-  const int b = idx / p.nqblk;
+  int qblk_i, b;
+  split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, b);
+  const int qblk = p.nqblk - 1 - qblk_i;
   const int h = hk * G + gq;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
@@ -407,8 +408,9 @@ __global__ __launch_bounds__(kBgThreads) void dq_big_kernel(const BwdParams p) {
   idx /= p.Hk;
   const int gq = idx % G;
   idx /= G;
-  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
-  const int b = idx / p.nqblk;
+  int qblk_i, b;
+  split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, b);
+  const int qblk = p.nqblk - 1 - qblk_i;
   const int h = hk * G + gq;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
@@ -631,8 +633,8 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_big_kernel(const BwdParams p)
   const int nsplit = p.nsplit;
   const int qsplit = idx % nsplit;                    // which share of the key block's tiles (rfa_bwd.hip: kWide)
   idx /= nsplit;
-  const int kblk = idx % p.nkblk;
-  const int b = idx / p.nkblk;
+  int kblk, b;
+  split_block_batch<RFA_BATCH_FAST_KV>(idx, p.nkblk, p.B, kblk, b);
   const int h0 = hk * G;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
@@ -973,8 +975,8 @@ __global__ __launch_bounds__(kBgThreads) void dkdv_fused_big_kernel(const BwdPar
   const int nsplit = p.nsplit;
   const int qsplit = idx % nsplit;
   idx /= nsplit;
-  const int kblk = idx % p.nkblk;
-  const int b = idx / p.nkblk;
+  int kblk, b;
+  split_block_batch<RFA_BATCH_FAST_KV>(idx, p.nkblk, p.B, kblk, b);
   const int h0 = hk * G;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);

@@ -115,8 +115,9 @@ __global__ __launch_bounds__(kDqThreads, 2) void dq_kernel(const BwdParams p) {
   idx /= p.Hk;
   const int gq = idx % G;
   idx /= G;
-  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
-  const int b = idx / p.nqblk;
+  int qblk_i, b;
+  split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, b);
+  const int qblk = p.nqblk - 1 - qblk_i;
   const int h = hk * G + gq;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
@@ -410,13 +411,15 @@ template <int kD> constexpr int kv_smem() {        // 129 KiB (65 KiB at kD = 64
 // a causal launch at Hk = 8, so the tile range of a key block can be split over p.nsplit workgroups whose
 // partials (fp32, workspace) are summed by reduce_kernel (rfa_api.cpp).
 // kDrop: dropout — dV takes the dropped, rescaled probabilities, dS the masked dP (128-key form without spill / window)
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide, bool kDrop = false>
+// kBal (round 6, kWide only): the BALANCED causal schedule — see "balanced schedule" below the work decode
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide, bool kDrop = false, bool kBal = false>
 __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_t* smem = (lds_t*)smem_raw;
   static_assert(!kSpill || (kD == 128 && !kWin), "the dS spill path: head dim 128, no window");
   static_assert(!kWide || ((kD == 128 || kD == 64) && kFullD && !kWin), "the 256-key form: head dim 128 / 64 exactly, no window");
   static_assert(!kDrop || (!kSpill && !kWin && !kWide), "dropout: the plain 128-key instances");
+  static_assert(!kBal || kWide, "the balanced schedule: the 256-key form");
   constexpr int kKeys = kWide ? 2 * kKvKeys : kKvKeys;       // keys per workgroup
   typedef HeadGeo<kD> Geo;
   constexpr int kRowBytes = Geo::kRowBytes;                  // (shadows the 128-wide namespace constant)
@@ -448,23 +451,58 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int G = p.H / p.Hk;
   const int hk = idx % p.Hk;
   idx /= p.Hk;
-  const int nsplit = kWide ? p.nsplit : 1;
+  const int nsplit = (kWide && !kBal) ? p.nsplit : 1;
   const int qsplit = idx % nsplit;                    // which part of the key block's tile range
   idx /= nsplit;
-  const int kblk = idx % p.nkblk;
-  const int b = idx / p.nkblk;
+  int wblk, b;                                        // the key block (kBal: the workgroup's role, below) and the batch
+  if (kBal) {
+    wblk = idx % p.nkblk;
+    b = idx / p.nkblk;
+  } else {
+    split_block_batch<RFA_BATCH_FAST_KV>(idx, p.nkblk, p.B, wblk, b);
+  }
   const int h0 = hk * G;                              // the G query heads h0 .. h0+G-1 share this K/V head
+  // ---- balanced schedule (kBal; rfa_api.cpp: dense causal self-attention blocks, lq == lk a multiple of 512 rows) ----
+  // A causal launch's key blocks differ 1 : nkb in length.  Sharing every block's tile range between ns workgroups
+  // balances the launch but writes ns fp32 partials per key and needs reduce_kernel (134 MB written + read per launch
+  // whatever the sequence length: at B 8 x S 1024 that costs more than the imbalance).  Here the nkb workgroups of a
+  // (batch, K/V head) each take EXACTLY T/2 + 2 of the T = 4 nkb Q/dO tiles' worth of work, and only the lower half of
+  // the key blocks is shared — by exactly two workgroups, which add their partials between themselves:
+  //   A_j (j < nkb/2): key block j — its top 4 + 4j tiles walking DOWN from the last tile, then its first tiles walking
+  //                    UP from its diagonal (tiles 4j .. T/2 - 3)
+  //   B_j            : first ALL of key block nkb-1-j (its 4 + 4j tiles, down from the last tile; stored directly), then
+  //                    the middle of key block j (tiles T-5-4j down to T/2-2)
+  // At any moment the workgroups of a K/V head (one XCD's L2) are on at most two different tiles: the one the downward
+  // walkers share and the one the upward walkers share.  Key block j's two partial sums meet in its LAST arriver: the first
+  // to finish publishes its accumulators (fp32, write-through) and a flag, the other adds them to its own registers
+  // (a + b == b + a: the result does not depend on who came first) and stores the block — no reduce pass.
+  const int bal_half = p.nkblk >> 1;
+  const bool bal_b = kBal && wblk < bal_half;
+  const int bal_j = kBal ? (bal_b ? wblk : wblk - bal_half) : 0;
+  const int nseg = bal_b ? 2 : 1;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);
   const SeqSpan ks = resolve_span(p.cu_k, b, p.Sk, p.k_half);
   const int lq = qs.len, lk = ks.len;
-  const int kwg0 = kblk * kKeys;
-  if (kwg0 >= lk) return;
   const int off = lk - lq;
-  const int kw0 = kwg0 + kbw * 32;
-  const int krow = kw0 + l31;
   const int64_t qbatch = p.cu_q ? 0 : (int64_t)b;
   const int64_t kbatch = p.cu_k ? 0 : (int64_t)b;
+  // one pass per key block of this workgroup (two for a type-B workgroup of the balanced schedule, else one)
+#pragma unroll 1
+  for (int seg = 0; seg < nseg; ++seg) {
+  // (kBal: every lane-derived value below is formed again per pass from an opaque copy of the thread index — hoisted
+  //  out of this loop by the compiler they would stay live across the epilogue and push its 128 accumulators to scratch)
+  int tid_pass = threadIdx.x;
+  if (kBal) asm volatile("" : "+v"(tid_pass));
+  const int tid = tid_pass;
+  const int lane = tid & 63;
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+  const int kblk = kBal ? ((bal_b && seg == 0) ? p.nkblk - 1 - bal_j : bal_j) : wblk;
+  const int kwg0 = kblk * kKeys;
+  if (kwg0 >= lk) return;
+  const int kw0 = kwg0 + kbw * 32;
+  const int krow = kw0 + l31;
 
   const T* kbase = (const T*)p.k + kbatch * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)hk * p.k_st.head;
   const T* vbase = (const T*)p.v + kbatch * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)hk * p.v_st.head;
@@ -493,8 +531,21 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // nsplit, ...; may be none: it then stores zeros).  Interleaved rather than contiguous ranges so that all
   // workgroups of a launch — whatever their key block and split — walk down the SAME tiles at about the same
   // time and the L2 serves a Q/dO tile to all of them (contiguous halves: 2.4x the HBM fetch, measured).
-  const int jtop = jt1 - 1 - qsplit;
-  const int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
+  int jtop = jt1 - 1 - qsplit;
+  int ntile_q = jtop >= jt0 ? (jtop - jt0) / nsplit + 1 : 0;
+  // kBal: w_n1 tiles from jtop downward, then (type A) upward from w_j2
+  int w_n1 = 0x7fffffff, w_j2 = 0;
+  if (kBal) {
+    const int nt = p.nkblk * (kKeys / kKvQ);           // T: the 64-row Q/dO tiles of the sequence
+    const int n_top = 4 + 4 * bal_j, n_low = nt / 2 - 2 - 4 * bal_j;
+    if (!bal_b) {
+      jtop = nt - 1; w_n1 = n_top; w_j2 = 4 * bal_j; ntile_q = n_top + n_low;
+    } else if (seg == 0) {
+      jtop = nt - 1; ntile_q = n_top;
+    } else {
+      jtop = nt - 5 - 4 * bal_j; ntile_q = n_low;
+    }
+  }
 
   const int sc = tid % kChunks;
   const int sr = tid / kChunks;               // 0 .. kRowsPerPass-1
@@ -559,6 +610,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // jt0, head after head, spreads them over the whole sequence and every tile is re-fetched from HBM per
   // workgroup: 3.5x the fabric traffic, measured.)
   int ld_g = 0, ld_j = jtop > 0 ? jtop : 0;           // (head in group, tile) the next load_tile() fetches
+  int ld_c = 0;                                       // kBal: tiles the loader has finished
   auto load_tile = [&]() {
     const int j = RFA_KV_X_LOAD == 2 ? 0 : ld_j;       // (2: measurement, every load hits the same hot tile)
     const T* qbase = qbase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.q_st.head;
@@ -567,7 +619,12 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
     if (++ld_g >= G) {
       ld_g = 0;
-      ld_j -= nsplit;
+      if (kBal) {
+        ++ld_c;
+        ld_j = ld_c == w_n1 ? w_j2 : (ld_c < w_n1 ? ld_j - 1 : ld_j + 1);
+      } else {
+        ld_j -= nsplit;
+      }
     }
     int rows = lq - j * kKvQ;
     rows = rows < kKvQ ? rows : kKvQ;
@@ -671,7 +728,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   if (wave >= kKvWaves / 2) __builtin_amdgcn_s_setprio(1);   // the half dispatched second (loses every VALU arbitration)
 #endif
   const int ntile = ntile_q * G;
-  int j = jtop, cg = 0;
+  int j = jtop, cg = 0, jc = 0;
   for (int f = 0; f < ntile; ++f) {
     if (RFA_KV_X_LOAD && f + 1 < ntile) load_tile();
     int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
@@ -867,7 +924,12 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (f + 1 < ntile) write_tile();
     if (++cg >= G) {
       cg = 0;
-      j -= nsplit;
+      if (kBal) {
+        ++jc;
+        j = jc == w_n1 ? w_j2 : (jc < w_n1 ? j - 1 : j + 1);
+      } else {
+        j -= nsplit;
+      }
     }
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
 #pragma unroll
@@ -902,10 +964,65 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       for (int r = 0; r < 16; ++r) fin[dblk][r] += xbuf[rslot + (dblk * 16 + r) * 64 + lane];
   }
 
-  if (krow >= lk) return;
+  // ---- kBal: key block j's two partial sums meet in whichever of A_j / B_j arrives last
+  bool do_final = true, add_partner = false;
+  const __attribute__((address_space(1))) char* pair_src = nullptr;     // this lane's 16 bytes of the partner's slot
+  if (kBal && !(bal_b && seg == 0)) {
+    typedef __attribute__((address_space(1))) unsigned gu32;
+    const int64_t pid = ((int64_t)b * p.Hk + hk) * bal_half + bal_j;
+    gu32* flag = (gu32*)(p.pair_flags + pid);
+    __attribute__((address_space(3))) unsigned* role_w = (__attribute__((address_space(3))) unsigned*)(smem + kOffStat);
+    if (tid == 0) {
+      unsigned seen = 0u;                                // 0 -> 1: this workgroup is first and will publish
+      __hip_atomic_compare_exchange_strong(flag, &seen, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *role_w = seen;
+    }
+    __syncthreads();
+    const unsigned role = __builtin_amdgcn_readfirstlane(*role_w);
+    // this wave's slice of the pair's slot: [tensor][dblk][jj][lane] x 16 bytes — the partner's wave of the same key
+    // block index reads lane for lane what its twin wrote (whole 1 KiB wave-instructions)
+    constexpr int kSlotWave = 2 * kNB * 4 * 1024;
+    char* slot = (char*)p.pair_ws + (pid * kKvWaves + wave) * (int64_t)kSlotWave;
+    pair_src = (const __attribute__((address_space(1))) char*)slot + lane * 16;
+    if (role == 0u) {
+      // publish (the guide's R1 recipe): payload write-through (sc1) so that no release fence is needed, every storing
+      // wave drains its stores, ONE lane then stores the flag at agent scope
+      const buf_rsrc_t rs = make_rsrc(slot, kSlotWave);
+#pragma unroll
+      for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = which ? dv[dblk][4 * jj + e] : dk[dblk][4 * jj + e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), rs,
+                                                   ((which * kNB + dblk) * 4 + jj) * 1024 + lane * 16, 0, 16);
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      do_final = false;
+    } else {
+      if (wave == 0) {                                   // ONE wave polls ONE word, relaxed; ONE acquire after the match
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 2u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) __builtin_trap();    // (the publisher is resident and inside its epilogue: microseconds)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      add_partner = true;                                // (added where the block is stored, below: the accumulators stay read-only)
+    }
+  }
+
+  if (!kBal && krow >= lk) return;
   const int64_t orow = ks.row0 + krow;
   // parity form: parity 0 stores dK, parity 1 dV; kWide: this wave stores both (which = 0: dK, 1: dV)
   const int64_t soff = (int64_t)qsplit * p.kv_split_stride;      // this split's partial (elements; 0 without a split)
+  if (do_final && krow < lk)
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     if (!kWide && which != par) continue;
@@ -913,6 +1030,25 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     const float sc_ = which ? 1.f : p.scale;
     const Strides st = which ? p.dv_st : p.dk_st;
     const int64_t eoff = kbatch * st.batch + orow * st.row + (int64_t)hk * st.head + soff;
+    // kBal, last arriver of a shared key block: the partner's fp32 partial of this tensor (one tensor's 16 loads in flight:
+    // 64 plain registers; the MFMA accumulator tuples are only read — adding into them under the role branch made hipcc
+    // shuffle whole tuples through scratch at the merge)
+    f32x4 py[kBal ? kNB : 1][4];
+    if (kBal) {
+#pragma unroll
+      for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) py[dblk][jj][e] = 0.f;
+      if (add_partner) {
+#pragma unroll
+        for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+            py[dblk][jj] = *(const __attribute__((address_space(1))) f32x4*)(pair_src + ((which * kNB + dblk) * 4 + jj) * 1024);
+      }
+    }
     if (p.kv_f32) {
       // fp32 store straight into the caller's accumulator slot (overwrite): lane (key, g) holds, per
       // (dblk, jj), the 4 consecutive columns 32 dblk + 8 jj + 4 g .. +3
@@ -925,7 +1061,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
           if (kFullD || d0 < p.D) {
             f32x4 x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = fin[dblk][4 * jj + e] * sc_;
+            for (int e = 0; e < 4; ++e) x[e] = (kBal ? fin[dblk][4 * jj + e] + py[dblk][jj][e] : fin[dblk][4 * jj + e]) * sc_;
             if (p.kv_accum) {                      // (a later query-head fraction of a chunked launch sequence)
               const f32x4 old = *(f32x4*)(ob + d0);
 #pragma unroll
@@ -934,10 +1070,33 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
             *(f32x4*)(ob + d0) = x;
           }
         }
+    } else if (kBal) {
+      // store_rows16 with the partner's values added (same half-wave exchange, same 16-byte stores)
+      T* row_ptr = (T*)(which ? p.dv : p.dk) + eoff;
+#pragma unroll
+      for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          f32x4 x0, x1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x0[e] = (fin[dblk][8 * m + e] + py[dblk][2 * m][e]) * sc_;
+            x1[e] = (fin[dblk][8 * m + 4 + e] + py[dblk][2 * m + 1][e]) * sc_;
+          }
+          const vec4<T> h0 = __builtin_convertvector(x0, vec4<T>);
+          const vec4<T> h1 = __builtin_convertvector(x1, vec4<T>);
+          i32x2 a_ = __builtin_bit_cast(i32x2, h0), b_ = __builtin_bit_cast(i32x2, h1);
+          auto r0 = __builtin_amdgcn_permlane32_swap(a_[0], b_[0], false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(a_[1], b_[1], false, false);
+          i32x4 w;
+          w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];
+          *(i32x4*)(row_ptr + 32 * dblk + 16 * m + 8 * g) = w;
+        }
     } else {
       store_rows16<T, kFullD, kNB>((T*)(which ? p.dv : p.dk) + eoff, fin, sc_, g, p.D, true);
     }
   }
+  }   // segment loop
 }
 
 template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false>
@@ -950,14 +1109,21 @@ static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
-template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false, bool kDrop = false>
+template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false, bool kDrop = false, bool kBal = false>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop>, kv_smem<kD>(), attr_done)) return rc;
+  if (int rc = opt_in_dynamic_lds((const void*)dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop, kBal>, kv_smem<kD>(), attr_done)) return rc;
   // one workgroup per (key block, K/V head) [x tile-range split of the 256-key form]
-  const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B * (kWide ? p.nsplit : 1);
+  const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B * ((kWide && !kBal) ? p.nsplit : 1);
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
+  if (kBal) {
+    // the pair flags are polled words: zeroed before EVERY launch (a memset node in front of the kernel, graph-safe)
+    if (hipMemsetAsync(p.pair_flags, 0, (size_t)p.B * p.Hk * (p.nkblk / 2) * sizeof(unsigned), stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return kLaunchFailed;
+    }
+  }
+  hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop, kBal>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
@@ -997,6 +1163,13 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   if (p.wide && p.D == 64)                        // round 5: the 256-key form for head dim 64 (7-GEMM backward: no dS hand-off there)
     return dtype == 0 ? launch_dkdv_t<bf16_t, 64, true, false, false, true>(p, stream)
                       : launch_dkdv_t<f16_t, 64, true, false, false, true>(p, stream);
+  if (p.wide && p.bal) {                          // round 6: the balanced causal schedule (rfa_api.cpp: head dim 128 only)
+    if (p.ds != nullptr)
+      return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true, false, true>(p, stream)
+                        : launch_dkdv_t<f16_t, 128, true, true, false, true, false, true>(p, stream);
+    return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, false, false, true, false, true>(p, stream)
+                      : launch_dkdv_t<f16_t, 128, true, false, false, true, false, true>(p, stream);
+  }
   if (p.wide) {                                   // rfa_api.cpp: only for head dim 128 / 64 without a window
     if (p.ds != nullptr)
       return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true>(p, stream)

@@ -169,6 +169,32 @@ __device__ __forceinline__ vec8<T> zero8() {
 // key / query index of C-layout register r for lane group g inside a 32-row block
 __device__ __forceinline__ int crow(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
+// (block, batch) of a launch's remaining blockIdx digits.  Workgroups are dispatched in blockIdx order and the kernels number
+// a sequence's blocks heaviest first (causal).  Round 6, dK/dV kernels: the BATCH index runs faster than the block index.
+// With the batch as the slowest digit a multi-batch launch dealt all key blocks of sequence 0 — heavy to light — before
+// the heavy blocks of sequence 1: with more workgroups than CUs the late sequences' heavy blocks started last and the
+// launch ended in a long tail (B 4 x S 4096, unshared dK/dV plan: backward 1.95 -> 1.60 ms, B 8 x S 2048 1.05 -> 0.88).
+// Batch-fastest deals the heaviest blocks of ALL sequences first — the order the launch plans' makespan estimate
+// (rfa_api.cpp) assumes.  The query-block kernels (forward, dQ) have 4 x the workgroups, whose tail is short anyway, and
+// lose 2 - 6 % of their K/V tile reuse in the L2 when co-resident workgroups belong to different sequences: they keep the
+// batch as the slowest digit (profiles/r06_batch_order.md).
+#ifndef RFA_BATCH_FAST_KV
+#define RFA_BATCH_FAST_KV 1
+#endif
+#ifndef RFA_BATCH_FAST_Q
+#define RFA_BATCH_FAST_Q 0
+#endif
+template <bool kBatchFast>
+__device__ __forceinline__ void split_block_batch(int idx, int nblk, int nbatch, int& blk, int& b) {
+  if (kBatchFast) {
+    b = idx % nbatch;
+    blk = idx / nbatch;
+  } else {
+    blk = idx % nblk;
+    b = idx / nblk;
+  }
+}
+
 struct Strides {
   int64_t batch, row, head;
 };

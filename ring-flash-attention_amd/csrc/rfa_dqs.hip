@@ -91,8 +91,9 @@ __global__ __launch_bounds__(DsGeo<kW>::kThreads, 2) void dq_ds_kernel(const Bwd
   idx /= p.Hk;
   const int gq = idx % G;
   idx /= G;
-  const int qblk = p.nqblk - 1 - (idx % p.nqblk);
-  const int b = idx / p.nqblk;
+  int qblk_i, b;
+  split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, b);
+  const int qblk = p.nqblk - 1 - qblk_i;
   const int h = hk * G + gq;
 
   // dense, or packed sequences (cu_seqlens), whole or the front / back half of every sequence

@@ -114,8 +114,9 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   const int nsplit = p.kv_nsplit > 1 ? p.kv_nsplit : 1;      // split-KV launch: which share of the key tiles
   const int split = idx % nsplit;
   idx /= nsplit;
-  const int qblk = p.nqblk - 1 - (idx % p.nqblk);   // heavy (late) causal blocks first
-  const int b = idx / p.nqblk;
+  int qblk_i, b;
+  split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, b);
+  const int qblk = p.nqblk - 1 - qblk_i;            // heavy (late) causal blocks first
   const int h = hk * G + gq;
 
   const SeqSpan qs = resolve_span(p.cu_q, b, p.Sq, p.q_half);

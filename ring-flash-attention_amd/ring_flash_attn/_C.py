@@ -10,13 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RFA_LIB_PATH: A/B tooling only (tools/ab_variants.py builds tuning variants of the same library)
 LIB_PATH = os.environ.get("RFA_LIB_PATH") or os.path.join(_HERE, "librfa_hip.so")
 
-RFA_ABI_VERSION = 5
+RFA_ABI_VERSION = 6
 RFA_BF16, RFA_F16 = 0, 1
 HALF_FULL, HALF_FRONT, HALF_BACK = 0, 1, 2
 BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
 BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
 BWD_KV_OVERWRITE = 16     # dk_acc / dv_acc are overwritten (dq_acc still follows acc_init)
-DKDV_AUTO, DKDV_128, DKDV_256 = 0, 1, 2
+DKDV_AUTO, DKDV_128, DKDV_256, DKDV_BAL = 0, 1, 2, 3
 FWD_AUTO, FWD_8x32, FWD_4x32 = 0, 1, 3        # (2: a retired experiment, RFA_ERR_ARGS)
 
 

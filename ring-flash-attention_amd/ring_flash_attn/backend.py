@@ -455,13 +455,15 @@ def _spill_frac() -> float:
 
 
 def _plan_overrides():
-    """(dkdv_form, dkdv_nsplit) from the tuning / test switches config.dkdv_wide (RFA_DKDV_WIDE=0|1) and
+    """(dkdv_form, dkdv_nsplit) from the tuning / test switches config.dkdv_wide (RFA_DKDV_WIDE=0|1|2; 2 = the balanced causal schedule) and
     config.dkdv_nsplit (RFA_DKDV_NSPLIT=n; n > 0 also forces the 256-key form); (AUTO, 0) when unset"""
     c = config.get()
     form = _C.DKDV_AUTO
     if c.dkdv_wide == 0:
         form = _C.DKDV_128
-    elif c.dkdv_nsplit > 0 or c.dkdv_wide == 1:
+    elif c.dkdv_wide == 2 and c.dkdv_nsplit <= 0:
+        form = _C.DKDV_BAL               # (the balanced causal schedule where the call is eligible, else the library's choice)
+    elif c.dkdv_nsplit > 0 or c.dkdv_wide >= 1:
         form = _C.DKDV_256               # (forced: the C plan takes form == 256 as given; nsplit 0 = its own choice)
     return form, c.dkdv_nsplit
 

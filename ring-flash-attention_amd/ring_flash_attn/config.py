@@ -88,7 +88,7 @@ class Config:
     ds_spill_max_bytes: int = 9 * _GiB // 2
     ds_spill_max_frac: float = 0.5
     fwd_form: str = "auto"
-    dkdv_wide: int = -1          # -1 unset, 0 the 128-key form, 1 the 256-key form
+    dkdv_wide: int = -1          # -1 unset, 0 the 128-key form, 1 the 256-key form, 2 the balanced causal schedule (where eligible)
     dkdv_nsplit: int = 0         # 0 unset
     fwd_kv_nsplit: int = 0       # 0: chosen from the shapes; 1: never split; 2..8 forced
     tuning_log: bool = False
@@ -133,7 +133,7 @@ class Config:
         if (r := get("RFA_FWD_FORM")) is not None:
             c.fwd_form = _choice("RFA_FWD_FORM", r, ("auto", "8x32", "4x32"))
         if (r := get("RFA_DKDV_WIDE")) is not None:
-            c.dkdv_wide = 1 if _bool("RFA_DKDV_WIDE", r) else 0
+            c.dkdv_wide = 2 if r.strip() == "2" else (1 if _bool("RFA_DKDV_WIDE", r) else 0)
         if (r := get("RFA_DKDV_NSPLIT")) is not None:
             c.dkdv_nsplit = _int("RFA_DKDV_NSPLIT", r)
         if (r := get("RFA_FWD_KV_NSPLIT")) is not None:

@@ -248,9 +248,34 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
         assert lib.rfa_bwd_plan(C.byref(a), C.byref(f), C.byref(n), C.byref(g)) == 0
         return f.value, n.value
 
-    # headline (GQA 32:8, S = 8192): 256-key form, two workgroups per key block -> two fp32 partial sets
-    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_256, 2)
-    assert ws(args(1, 8192, 8192, 32, 8, causal=True)) == 2 * unit32(8192, 8)
+    # headline (GQA 32:8, S = 8192, dense causal self-attention): round 6's BALANCED schedule of the 256-key form — 256 equal
+    # workgroups, the 16 lower key blocks of every (batch, K/V head) shared by two workgroups that add their fp32 partials
+    # between themselves: one 256-key (dK, dV) pair slot + one flag word per shared block, no reduction pass
+    pair_ws = lambda B, S, Hk, D=128: (B * Hk * (S // 512) * 4 + 255) // 256 * 256 + B * Hk * (S // 512) * 2 * 256 * D * 4
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
+    assert ws(args(1, 8192, 8192, 32, 8, causal=True)) == pair_ws(1, 8192, 8) == 512 + unit32(8192, 8) // 2
+    # ... named plans still run: the shared-range plan of rounds 2-5 (two fp32 partial sets + reduce_kernel) ...
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True, form=_C.DKDV_256, nsplit=2)) == (_C.DKDV_256, 2)
+    assert ws(args(1, 8192, 8192, 32, 8, causal=True, form=_C.DKDV_256, nsplit=2)) == 2 * unit32(8192, 8)
+    # ... and the balanced schedule by name where the estimate would not pick it (MHA: 1024 workgroups balance unshared)
+    assert plan(args(1, 8192, 8192, 32, 32, causal=True, form=_C.DKDV_BAL)) == (_C.DKDV_BAL, 1)
+    # not eligible -> the field reads as AUTO: no mask, sequences that are not whole pairs of 256-key blocks, Sq != Sk,
+    # packed sequences, += into accumulators, two-phase calls, a window, another head dim
+    assert plan(args(1, 8192, 8192, 32, 8, form=_C.DKDV_BAL)) == (_C.DKDV_256, 1)
+    assert plan(args(1, 8192 - 256, 8192 - 256, 32, 8, causal=True, form=_C.DKDV_BAL))[0] == _C.DKDV_256
+    assert plan(args(1, 4096, 8192, 32, 8, causal=True, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
+    assert plan(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True, acc=True, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True, phases=_C.BWD_COMPUTE, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True, window=(512, 0), form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
+    assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True, form=_C.DKDV_BAL)) == (_C.DKDV_256, 2)
+    # ... overwritten accumulators (the kernel stores fp32 itself) are
+    a_ow = args(1, 8192, 8192, 32, 8, causal=True, acc=True)
+    a_ow.acc_init = 1
+    assert plan(a_ow) == (_C.DKDV_BAL, 1)
+    # ... under-filled launches keep the shared-range plans (the balanced schedule has B * Hk * S / 256 workgroups)
+    assert plan(args(1, 8192, 8192, 8, 2, causal=True))[0] == _C.DKDV_256
+    assert plan(args(1, 4096, 4096, 32, 8, causal=True))[0] == _C.DKDV_256
     # dS scratch: rectangular rows when every block is visited, packed triangular rows for a dense causal call
     assert ds(args(1, 8192, 8192, 32, 8)) == 32 * 256 * 256 * 2048
     assert ds(args(1, 8192, 8192, 32, 8, causal=True)) == 32 * (256 * 257 // 2) * 2048
@@ -297,22 +322,30 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert plan(args(1, 1024, 1024, 4, 2, form=_C.DKDV_256)) == (_C.DKDV_256, 8)
     # short sequences with 8 K/V heads (profiles/history/r04_dkdv_plans_short_sequences.txt, re-measured in round 6): <= 1024 the
     # 256-key form unshared; 2048 and 4096 with 256 workgroups: two shares (the causal imbalance of ONE round)
-    assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_256, 1)
+    # round 6, second session (profiles/r06_balanced_schedule.md): ONE round of the chip (256 workgroups) runs the balanced
+    # schedule from 1024 rows on; 512-row sequences (two key blocks) and launches of several rounds (whose heaviest-first
+    # order — batch index fastest — balances them without any sharing) stay unshared
+    assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
     assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_256, 1)
-    assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_256, 2)
-    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
+    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
+    assert plan(args(4, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 1)
+    assert plan(args(2, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_256, 1)
     # the plan is a pure function of the shapes: asking twice (memoised) gives the same answer
-    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
     # ... the process environment does not reach the library
     monkeypatch.setenv("RFA_DKDV_WIDE", "0")
     monkeypatch.setenv("RFA_DKDV_NSPLIT", "3")
-    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_256, 2)
+    assert plan(args(1, 8192, 8192, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
     # ... it is translated once per backward by the Python backend (tests / tuning)
     assert BK._plan_overrides() == (_C.DKDV_128, 3)
     monkeypatch.setenv("RFA_DKDV_WIDE", "1")
     assert BK._plan_overrides() == (_C.DKDV_256, 3)
-    monkeypatch.delenv("RFA_DKDV_WIDE")
+    monkeypatch.setenv("RFA_DKDV_WIDE", "2")                 # (a share count names the shared-range plan)
+    assert BK._plan_overrides() == (_C.DKDV_256, 3)
     monkeypatch.delenv("RFA_DKDV_NSPLIT")
+    assert BK._plan_overrides() == (_C.DKDV_BAL, 0)
+    monkeypatch.delenv("RFA_DKDV_WIDE")
     assert BK._plan_overrides() == (_C.DKDV_AUTO, 0)
     # ---- ABI 5: the dS hand-off runs in head-group chunks over a scratch smaller than the whole hand-off
     def chunks(a, scratch_bytes):

@@ -508,6 +508,100 @@ def test_dkdv_256_key_form_with_query_range_splits(monkeypatch, nsplit, Sq, Sk, 
                 _check(f"nsplit={nsplit} spill={spill} {mode}.{n} vs 128-key form", a_, b_.float(), 0, kind="grad")
 
 
+@pytest.mark.parametrize("S,B,H,Hk,dtype", [
+    (512, 2, 4, 2, torch.bfloat16),       # ONE pair of key blocks per (batch, K/V head): A_0 / B_0 only
+    (1024, 1, 4, 1, torch.bfloat16),      # nkb = 4; one K/V head: the two workgroups of a pair sit on DIFFERENT XCDs (agent-scope hand-off)
+    (1536, 1, 4, 2, torch.float16),       # nkb = 6 (odd half), fp16
+    (2048, 2, 8, 2, torch.bfloat16),      # nkb = 8, G = 4, batch
+])
+def test_dkdv_balanced_causal_schedule(monkeypatch, S, B, H, Hk, dtype):
+    """Round 6: the balanced causal schedule of the 256-key dK/dV form (csrc/rfa_bwd.hip kBal, RFA_DKDV_BAL) — every workgroup
+    of a dense causal self-attention block walks the same number of Q/dO tiles, a key block of the lower half is shared by
+    two workgroups whose fp32 partials meet in the later one through an agent-scope flag — forced onto small shapes (production
+    picks it for launches that fill the chip): plain io outputs and overwritten fp32 accumulators run it, with and without
+    the dS hand-off; `+=` accumulators and two-phase calls are not eligible and must run what they ran before.  Against the
+    CPU oracle, against the 128-key form (same math, other summation order), run to run (bit-identical: a + b == b + a), and
+    with dQ bit-identical to the shared-range plan (the dS blocks do not depend on who computed them)."""
+    from oracle import flash_attn_ref as O
+    from ring_flash_attn import _C, config
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    D = 128
+    g = torch.Generator().manual_seed(S + H)
+    q = torch.randn(B, S, H, D, generator=g).to(dtype)
+    k = torch.randn(B, S, Hk, D, generator=g).to(dtype)
+    v = torch.randn(B, S, Hk, D, generator=g).to(dtype)
+    do = torch.randn(B, S, H, D, generator=g).to(dtype)
+    scale = D ** -0.5
+    ro, rl, _, _ = O._flash_attn_forward(q, k, v, 0.0, scale, True)
+    rdq, rdk, rdv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    O._flash_attn_backward(do, q, k, v, ro, rl, rdq, rdk, rdv, 0.0, scale, True)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    out = torch.empty_like(qd)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    be.fwd(qd, kd, vd, softmax_scale=scale, causal=True, out=out, lse=lse)
+    delta = torch.empty_like(lse)
+    be.bwd_preprocess(dod, out, delta)
+    kw = dict(softmax_scale=scale, causal=True)
+
+    def plan_of(**extra):
+        a = _C.BwdArgs()
+        a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype, a.causal, a.total_k = B, S, S, H, Hk, D, 0, 1, B * S
+        a.dkdv_form = _C.DKDV_BAL
+        for n_, v_ in extra.items():
+            setattr(a, n_, v_)
+        return be.bwd_plan(a)[0]
+
+    assert plan_of() == _C.DKDV_BAL and plan_of(dk_acc=1, dv_acc=1, acc_init=1) == _C.DKDV_BAL
+    assert plan_of(dk_acc=1, dv_acc=1) != _C.DKDV_BAL and plan_of(phases=_C.BWD_COMPUTE) != _C.DKDV_BAL
+
+    def run_all():
+        res = {}
+        dq, dk, dv = (torch.full_like(t, float("nan")) for t in (qd, kd, vd))
+        be.bwd(dod, qd, kd, vd, lse, delta, dq=dq, dk=dk, dv=dv, **kw)
+        res["plain"] = (dq, dk, dv)
+        dqa = torch.zeros((B, S, H, D), dtype=torch.float32, device=dev)
+        dka = torch.full((B, S, Hk, D), 5.0, dtype=torch.float32, device=dev)
+        dva = torch.full_like(dka, 5.0)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, acc_init=True,
+               phases=_C.BWD_KV_OVERWRITE, **kw)                                                 # fp32 slots, overwritten
+        res["overwrite"] = (dqa, dka, dva)
+        dqa = torch.zeros_like(dqa)
+        dka = torch.full_like(dka, 2.0)
+        dva = torch.full_like(dka, -1.0)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, **kw)          # += : not eligible
+        res["acc"] = (dqa, dka - 2.0, dva + 1.0)
+        dqa = torch.zeros_like(dqa)
+        dka = torch.full_like(dka, 1.0)
+        dva = torch.full_like(dka, 1.0)
+        part = be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, phases=_C.BWD_COMPUTE, **kw)
+        be.bwd(dod, qd, kd, vd, lse, delta, dq_acc=dqa, dk_acc=dka, dv_acc=dva, phases=_C.BWD_REDUCE, partials=part, **kw)
+        res["two_phase"] = (dqa, dka - 1.0, dva - 1.0)
+        return res
+
+    with config.override(dkdv_wide=0):
+        narrow = run_all()
+    with config.override(dkdv_wide=1, dkdv_nsplit=2):
+        shared = run_all()
+    for spill in (True, False):
+        with config.override(dkdv_wide=2, bwd_ds_spill=spill):
+            bal = run_all()
+            again = run_all()
+        for mode, got in bal.items():
+            _grads_ok(f"S={S} spill={spill} {mode}", got, (rdq, rdk, rdv))
+            for n, a_, b_ in zip(("dk", "dv"), got[1:], narrow[mode][1:]):
+                _check(f"S={S} spill={spill} {mode}.{n} vs 128-key form", a_, b_.float(), 0, kind="grad")
+            for n, a_, b_ in zip(("dq", "dk", "dv"), got, again[mode]):
+                assert torch.equal(a_, b_), f"S={S} spill={spill} {mode}.{n}: not bit-identical run to run"
+        if spill:
+            for mode in ("plain", "overwrite"):
+                assert torch.equal(bal[mode][0], shared[mode][0]), f"S={S} {mode}: dq differs from the shared-range plan"
+
+
 @pytest.mark.extended
 def test_ds_scratch_capped_by_free_memory_is_kept(monkeypatch):
     """ADVICE r4: a dS scratch that the free-memory fraction CAPPED when it was taken is smaller than the hand-off for ever;
