@@ -449,12 +449,17 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
         for (int64_t m = 0; m < mult; ++m) sizes.push_back(n * G);
       }
     }
+    // constants: the wide head dims keep round 6's first fit; the 128-wide kernels were re-fitted on the 80 shapes of
+    // profiles/r06_plan_sweep_final.md after the batch index became the fastest digit of the dK/dV work decode (which made
+    // the heaviest-first assumption of this estimate TRUE for multi-batch launches and the 128-key form — twice the
+    // workgroups — the best plan of several of them): worst chosen / best 1.03, mean 1.001
+    const double ovh = big ? 12.0 : (keys == 128 ? 6.0 : 8.0);
     double work = 0;
-    const double mk = plan_makespan(sizes, 12.0, &work);
+    const double mk = plan_makespan(sizes, ovh, &work);
     if (mk <= 0) return 0.0;
     double busy = work / (mk * kPlanSlots);
     busy = busy > 1 ? 1 : busy;
-    return mk * (keys == 128 && !big ? 0.7 : 1.0) * (1 + kPlanBusyGain * busy * busy) + (ns > 1 ? 12.0 : 0.0);
+    return mk * (keys == 128 && !big ? 0.65 : 1.0) * (1 + (big ? kPlanBusyGain : 0.3) * busy * busy) + (ns > 1 ? (big ? 12.0 : 8.0) : 0.0);
   };
   double best = -1;
   int wide = 0, best_ns = 1;
@@ -484,12 +489,16 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
   }
   // the balanced causal schedule, where the SHAPE allows it (the caller adds the call-level conditions: bwd_bal_eligible):
   // B * Hk * nkb equal workgroups of (T/2 + 2) G tile-times; half of them cross one key-block seam (a second prologue /
-  // epilogue) and every pair exchanges one partial: 18 tile-times of overhead on average instead of 12, no second pass
+  // epilogue) and every pair exchanges one partial: 14 tile-times of overhead on average instead of 8, no second pass
   int bal = 0;
   if (!only_wide && a->D == kHeadDim && a->causal && sq == sk && sk >= 512 && sk % 512 == 0) {
     const int nkb = sk / 256;
     std::vector<int> sizes((size_t)(mult * nkb), (2 * nkb + 2) * G);
-    bal = plan_cost(sizes, 18.0, 0.0) < 0.98 * best ? 1 : 0;
+    double work = 0;
+    const double mk = plan_makespan(sizes, 14.0, &work);
+    double busy = work / (mk * kPlanSlots);
+    busy = busy > 1 ? 1 : busy;
+    bal = mk * (1 + 0.3 * busy * busy) < 0.98 * best ? 1 : 0;
   }
   plan_store(h, (bal << 5) | (wide << 4) | best_ns);
   *ns_out = best_ns;
@@ -565,10 +574,15 @@ static bool bwd_needs_ws(const rfa_bwd_args* a) {
   return a->dk_acc != nullptr && !bwd_kv_direct(a);
 }
 
+static int64_t bwd_ds_head_blocks(const rfa_bwd_args* a);
 static bool bwd_spill_eligible(const rfa_bwd_args* a) {
-  return (a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && a->D >= kHeadDim && a->D <= 2 * kHeadDim &&
-         a->B > 0 && a->Sq > 0 && a->Sk > 0 && !(a->dropout_p > 0.f) &&
-         !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)));
+  if (!((a->cu_seqlens_q == nullptr) == (a->cu_seqlens_k == nullptr) && a->D >= kHeadDim && a->D <= 2 * kHeadDim &&
+        a->B > 0 && a->Sq > 0 && a->Sk > 0 && !(a->dropout_p > 0.f) &&
+        !(a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)))))
+    return false;
+  // one head's share of the scratch stays below 4 GiB: the dK/dV kernel addresses a dS block by a 32-bit scalar offset from
+  // its head's base (a single dense causal sequence of 65536 rows — 4.3 GB per head — runs the 7-GEMM form)
+  return bwd_ds_head_blocks(a) < ((int64_t)1 << 21);
 }
 
 // dS scratch rows: packed triangular for dense causal calls (block (qt, kb) is visited iff kb < qt + c), else

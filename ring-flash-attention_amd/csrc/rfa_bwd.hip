@@ -611,12 +611,21 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   // workgroup: 3.5x the fabric traffic, measured.)
   int ld_g = 0, ld_j = jtop > 0 ? jtop : 0;           // (head in group, tile) the next load_tile() fetches
   int ld_c = 0;                                       // kBal: tiles the loader has finished
+  // Round 6 (second session): the loader's addresses are RUNNING 64-bit scalars — the next head of the tile is one add, a
+  // new tile one multiply — instead of four base + head * stride + tile * 64 * stride products per tile-step.  The loop
+  // carried 250 scalar instructions per 64 MFMAs (two thirds of them this address arithmetic and the dS block address
+  // below), all in front of the tile's first fragment read, in BOTH waves of a SIMD at once behind the barrier.
+  const int64_t q_tile_e = (int64_t)kKvQ * p.q_st.row, do_tile_e = (int64_t)kKvQ * p.dout_st.row;
+  const float* st_base0 = wave ? dltbase0 : lsebase0;  // (wave 0 stages lse, wave 1 delta)
+  const int64_t st_head_e = wave ? p.delta_head : p.lse_head;
+  const T* ld_q = qbase0 + ld_j * q_tile_e;
+  const T* ld_do = dobase0 + ld_j * do_tile_e;
+  const float* ld_st = st_base0 + ld_j * kKvQ;
   auto load_tile = [&]() {
     const int j = RFA_KV_X_LOAD == 2 ? 0 : ld_j;       // (2: measurement, every load hits the same hot tile)
-    const T* qbase = qbase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.q_st.head;
-    const T* dobase = dobase0 + (int64_t)(RFA_KV_X_LOAD == 2 ? 0 : ld_g) * p.dout_st.head;
-    const float* lsebase = lsebase0 + (int64_t)ld_g * p.lse_head;
-    const float* dltbase = dltbase0 + (int64_t)ld_g * p.delta_head;
+    const T* qtile = RFA_KV_X_LOAD == 2 ? qbase0 : ld_q;
+    const T* dotile = RFA_KV_X_LOAD == 2 ? dobase0 : ld_do;
+    const float* sttile = ld_st;
     if (++ld_g >= G) {
       ld_g = 0;
       if (kBal) {
@@ -625,15 +634,22 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       } else {
         ld_j -= nsplit;
       }
+      ld_q = qbase0 + ld_j * q_tile_e;
+      ld_do = dobase0 + ld_j * do_tile_e;
+      ld_st = st_base0 + ld_j * kKvQ;
+    } else {
+      ld_q += p.q_st.head;
+      ld_do += p.dout_st.head;
+      ld_st += st_head_e;
     }
     int rows = lq - j * kKvQ;
     rows = rows < kKvQ ? rows : kKvQ;
     const int nq = rows > 0 ? ((rows - 1) * (int)p.q_st.row + p.D) * 2 : 0;
     const int ndo = rows > 0 ? ((rows - 1) * (int)p.dout_st.row + p.D) * 2 : 0;
-    const buf_rsrc_t rq = make_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
-    const buf_rsrc_t rdo = make_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
-    const dma_rsrc_t dq_ = make_dma_rsrc(qbase + (int64_t)j * kKvQ * p.q_st.row, nq);
-    const dma_rsrc_t ddo = make_dma_rsrc(dobase + (int64_t)j * kKvQ * p.dout_st.row, ndo);
+    const buf_rsrc_t rq = make_rsrc(qtile, nq);
+    const buf_rsrc_t rdo = make_rsrc(dotile, ndo);
+    const dma_rsrc_t dq_ = make_dma_rsrc(qtile, nq);
+    const dma_rsrc_t ddo = make_dma_rsrc(dotile, ndo);
 #pragma unroll
     for (int i = 0; i < kPasses; ++i) {
       if (kDma) {
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
     if (wave < 2) {                            // wave 0 stages lse, wave 1 delta (wave-uniform descriptor)
       // asynchronous like the tile DMA (counted by the wait in front of write_tile): a compiler-tracked load
       // would be protected with vmcnt(0) at its use and drain the dS spill stores issued after it every tile
-      const dma_rsrc_t rs = make_dma_rsrc((wave ? dltbase : lsebase) + j * kKvQ, rows > 0 ? rows * 4 : 0);
+      const dma_rsrc_t rs = make_dma_rsrc(sttile, rows > 0 ? rows * 4 : 0);
       statreg = buffer_load32_async(rs, lane * 4);
     }
     dma_stage ^= kKvTileBytes;
@@ -699,8 +715,9 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
   const int ds_lane = 16 * (16 * (l31 >> 2) + 4 * g + (l31 & 3));
   const int ds_nkb = ds_blocks(p.Sk, p.k_half);  // extents of the longest (half) sequence (= lk, lq when dense): rfa_dqs.hip
   // rows of the scratch: rectangular (p.ds_c >= ds_nkb) or packed triangular (dense causal), rfa_kernels.hpp
-  const int64_t ds_head_bytes = p.ds_head_blocks * kDsBlockBytes;
-  const char* ds_b = kSpill ? (const char*)p.ds + ds_base_blocks(p, b) * kDsBlockBytes : nullptr;
+  const int64_t ds_head_bytes = p.ds_head_blocks * kDsBlockBytes;   // (< 4 GiB: rfa_api.cpp bwd_spill_eligible — the block of a
+                                                                    //  store is addressed by a 32-bit scalar offset from its head's base)
+  const char* ds_b = kSpill ? (const char*)p.ds + ds_base_blocks(p, b) * kDsBlockBytes + (int64_t)h0 * ds_head_bytes : nullptr;
   const int64_t ds_g0 = (qs.row0 >> 5) + b;            // packed layout: global index of this (half) sequence's first row
   const int ds_kb = __builtin_amdgcn_readfirstlane(kblk * (kKeys / 32) + kbw);
 
@@ -729,13 +746,15 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #endif
   const int ntile = ntile_q * G;
   int j = jtop, cg = 0, jc = 0;
+  // dS scratch rows of tile j's two sub-tiles (blocks from the head's base: formed when j changes, not per tile-step) and
+  // the base of the current head's share of the scratch
+  int ds_roff0 = kSpill ? (int)ds_rowpart(p, 2 * j, ds_g0, ds_nkb) : 0;
+  int ds_rlen0 = kSpill ? ds_rowlen(p, 2 * j, ds_nkb) : 0;
+  const char* ds_hp = ds_b;
   for (int f = 0; f < ntile; ++f) {
     if (RFA_KV_X_LOAD && f + 1 < ntile) load_tile();
     int nact = 0;                                      // sub-tiles this wave computed (= pairs of spill stores issued)
     bool active = false;
-    // dS scratch rows of this tile's two sub-tiles (wave-uniform; once per tile, outside the MFMA blocks)
-    const int64_t ds_roff0 = kSpill ? ds_rowpart(p, 2 * j, ds_g0, ds_nkb) : 0;
-    const int ds_rlen0 = kSpill ? ds_rowlen(p, 2 * j, ds_nkb) : 0;
     // parity form: the one sub-tile t = par; kWide: both, one after the other (the sub-tile lives in address
     // bit 13 of the Q/dO fragment bases and bit 7 of the statistics base: toggled, not re-computed)
 #if RFA_KV_WIDE_UNROLL
@@ -855,13 +874,13 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
 #endif                        // 3 one store per sub-tile, 4 every store of a wave hits one L2-resident block
         auto spill = [&]() {
           if (!kSpill || RFA_SPILL_PROBE == 1) return;
-          const char* blk = ds_b + (int64_t)(h0 + cg) * ds_head_bytes +
-                            (ds_roff0 + (t ? ds_rlen0 : 0) + ds_kb) * kDsBlockBytes;
-          if (RFA_SPILL_PROBE == 4) blk = ds_b + (int64_t)(blockIdx.x * 8 + wave) * kDsBlockBytes;
-          const buf_rsrc_t rb = make_rsrc(blk, kDsBlockBytes);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds0), rb, ds_lane, 0, RFA_SPILL_AUX);
+          // one descriptor per head (its whole share of the scratch), the block as the store's SCALAR offset
+          unsigned boff = (unsigned)(ds_roff0 + (t ? ds_rlen0 : 0) + ds_kb) * (unsigned)kDsBlockBytes;
+          if (RFA_SPILL_PROBE == 4) boff = (unsigned)(blockIdx.x * 8 + wave) * (unsigned)kDsBlockBytes;
+          const buf_rsrc_t rb = make_rsrc(RFA_SPILL_PROBE == 4 ? (const char*)p.ds : ds_hp, -1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds0), rb, ds_lane, (int)boff, RFA_SPILL_AUX);
           if (RFA_SPILL_PROBE != 3)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds1), rb, ds_lane + 128, 0, RFA_SPILL_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ds1), rb, ds_lane + 128, (int)boff, RFA_SPILL_AUX);
         };
         if (RFA_SPILL_PROBE != 2) spill();
         if (RFA_KV_PRIO == 4 || RFA_KV_PRIO == 5) __builtin_amdgcn_s_setprio(1);
@@ -930,6 +949,13 @@ __global__ __launch_bounds__(kKvThreads, 2) void dkdv_kernel(const BwdParams p) 
       } else {
         j -= nsplit;
       }
+      if (kSpill) {
+        ds_roff0 = (int)ds_rowpart(p, 2 * j, ds_g0, ds_nkb);
+        ds_rlen0 = ds_rowlen(p, 2 * j, ds_nkb);
+        ds_hp = ds_b;
+      }
+    } else if (kSpill) {
+      ds_hp += ds_head_bytes;
     }
     aq ^= kKvTileBytes;                                // flip every stage-dependent address
 #pragma unroll

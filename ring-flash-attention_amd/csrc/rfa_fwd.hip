@@ -190,14 +190,21 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
     voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
     voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
   }
+  // (round 6: the tile addresses are running 64-bit scalars — load_tile() is called for consecutive tiles jt0, jt0 + 1, ... —
+  //  instead of two base + j * 64 * stride products per tile in front of the tile's first fragment read)
+  const int64_t k_tile_e = (int64_t)kFwdKV * p.k_st.row, v_tile_e = (int64_t)kFwdKV * p.v_st.row;
+  const T* ld_k = kbase + jt0 * k_tile_e;
+  const T* ld_v = vbase + jt0 * v_tile_e;
   auto load_tile = [&](int j, auto stage) {
     constexpr int kStage = decltype(stage)::value;
     int rows = lk - j * kFwdKV;
     rows = rows < kFwdKV ? rows : kFwdKV;
     const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + p.D) * 2 : 0;
     const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + p.D) * 2 : 0;
-    const T* kt = kbase + (int64_t)j * kFwdKV * p.k_st.row;
-    const T* vt = vbase + (int64_t)j * kFwdKV * p.v_st.row;
+    const T* kt = ld_k;
+    const T* vt = ld_v;
+    ld_k += k_tile_e;
+    ld_v += v_tile_e;
     if (kDma) {
       const dma_rsrc_t rk = make_dma_rsrc(kt, nk), rv = make_dma_rsrc(vt, nv);
 #pragma unroll

@@ -311,7 +311,7 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     # packed sequences: the form is chosen from the packed row count, and so is the scratch (ABI 5): total / 32 + B
     # query-block rows per head, each with the key blocks of the longest (half) sequence — 3.9 GB for the varlen
     # benchmark's (256, 7392, 544) pattern where B x the longest sequence would be 10.5 GB
-    assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 2 * unit32(8192, 8)
+    assert ws(args(3, 7392, 7392, 32, 8, varlen_total=8192)) == 3 * unit32(8192, 8)
     assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, causal=True)) == 32 * (256 + 3) * 231 * 2048
     assert ds(args(3, 7392, 7392, 32, 8, varlen_total=8192, halves=(2, 1))) == 32 * (256 + 3) * 116 * 2048
     # the overrides are arguments ...
@@ -323,10 +323,10 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     # short sequences with 8 K/V heads (profiles/history/r04_dkdv_plans_short_sequences.txt, re-measured in round 6): <= 1024 the
     # 256-key form unshared; 2048 and 4096 with 256 workgroups: two shares (the causal imbalance of ONE round)
     # round 6, second session (profiles/r06_balanced_schedule.md): ONE round of the chip (256 workgroups) runs the balanced
-    # schedule from 1024 rows on; 512-row sequences (two key blocks) and launches of several rounds (whose heaviest-first
-    # order — batch index fastest — balances them without any sharing) stay unshared
-    assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
-    assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_256, 1)
+    # schedule from 2048 rows on; shorter sequences the 128-key form (twice the workgroups), launches of several rounds
+    # (whose heaviest-first order — batch index fastest — balances them without any sharing) stay unshared
+    assert plan(args(8, 1024, 1024, 32, 8, causal=True)) == (_C.DKDV_128, 1)       # (512 key-block workgroups, dealt heaviest first)
+    assert plan(args(16, 512, 512, 32, 8, causal=True)) == (_C.DKDV_128, 1)
     assert plan(args(4, 2048, 2048, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
     assert plan(args(2, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_BAL, 1)
     assert plan(args(4, 4096, 4096, 32, 8, causal=True)) == (_C.DKDV_256, 1)

@@ -81,6 +81,9 @@ def bwd_points(quick):
     if not quick:
         for S, B, Hk in ((2048, 1, 8), (2048, 2, 4), (4096, 1, 2), (8192, 1, 1), (8192, 1, 2), (8192, 1, 4)):
             pts.append((f"S{S} B{B} Hk{Hk}", B, S, S, 4 * Hk, Hk, True))
+        for S, B, Hk in ((512, 16, 8), (1024, 16, 8), (1024, 12, 8), (2048, 8, 8), (2048, 3, 8), (4096, 4, 8), (8192, 2, 8), (1536, 3, 8),
+                         (8192, 1, 16), (8192, 1, 32), (5120, 1, 8), (1024, 4, 8), (2048, 2, 8)):              # multi-batch / partly filled (round 6, second session)
+            pts.append((f"S{S} B{B} Hk{Hk}", B, S, S, 4 * Hk if Hk < 32 else Hk, Hk, True))
         for S, B, Hk in ((3072, 2, 2), (6144, 1, 8), (1536, 4, 4), (8192, 1, 8), (16384, 1, 2)):      # validation (not fitted on)
             pts.append((f"S{S} B{B} Hk{Hk}", B, S, S, 4 * Hk, Hk, True))
         pts.append(("llama3 Sq2048 Sk8192 H16/8", 1, 2048, 8192, 16, 8, True))
@@ -156,6 +159,9 @@ def sweep(quick=False, log=print, dump=None):
         for ns in (1, 2) + ((3, 4, 6, 8) if S >= 1024 else ()):
             with config.override(dkdv_wide=1, dkdv_nsplit=ns):
                 forced[f"{'256' if D <= 128 else '128'}-key ns{ns}"] = _time(run, iters)
+        if D == 128 and causal and S == Sk and S % 512 == 0:             # the balanced causal schedule (round 6), where eligible
+            with config.override(dkdv_wide=2):
+                forced["balanced"] = _time(run, iters)
         chosen = min(chosen, _time(run, iters))
         bname = min(forced, key=forced.get)
         if dump is not None:
