@@ -211,7 +211,7 @@ typedef struct {
    *   dkdv_form   RFA_DKDV_AUTO: chosen from the shapes; RFA_DKDV_128: a workgroup owns 128 keys;
    *               RFA_DKDV_256: 256 keys (head dim 128 without a window only, otherwise ignored)
    *               RFA_DKDV_BAL (ABI 6): 256 keys in the balanced causal schedule — every workgroup of a dense causal
-   *               self-attention block (Sq == Sk, a multiple of 512 rows, head dim 128, single-phase call that writes
+   *               self-attention block (Sq == Sk, a multiple of 512 rows, head dim 128 or 64, single-phase call that writes
    *               dk / dv or overwrites dk_acc / dv_acc) does the same amount of work, key blocks of the lower half are
    *               shared by two workgroups that add their partials between themselves: no reduction pass.  Where the
    *               call is not eligible the field is read as RFA_DKDV_AUTO.  RFA_DKDV_256 with dkdv_nsplit > 0 names the

@@ -491,7 +491,7 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
   // B * Hk * nkb equal workgroups of (T/2 + 2) G tile-times; half of them cross one key-block seam (a second prologue /
   // epilogue) and every pair exchanges one partial: 14 tile-times of overhead on average instead of 8, no second pass
   int bal = 0;
-  if (!only_wide && a->D == kHeadDim && a->causal && sq == sk && sk >= 512 && sk % 512 == 0) {
+  if (!only_wide && !big && a->causal && sq == sk && sk >= 512 && sk % 512 == 0) {
     const int nkb = sk / 256;
     std::vector<int> sizes((size_t)(mult * nkb), (2 * nkb + 2) * G);
     double work = 0;
@@ -512,7 +512,7 @@ static int bwd_dkdv_cost_plan(const rfa_bwd_args* a, int hk_launch, bool only_wi
 // call in one launch that writes the final dK/dV (single phase, plain outputs or overwritten accumulators, all heads
 // at once) and a sequence of whole PAIRS of 256-key blocks.
 static bool bwd_bal_eligible(const rfa_bwd_args* a, bool whole_call) {
-  if (a->D != kHeadDim || !a->causal || a->cu_seqlens_q != nullptr || a->dropout_p > 0.f) return false;
+  if ((a->D != kHeadDim && a->D != 64) || !a->causal || a->cu_seqlens_q != nullptr || a->dropout_p > 0.f) return false;
   if (a->window && (a->window_left >= 0 || a->window_right >= 0)) return false;
   const int lq = eff_len(a->Sq, a->q_half), lk = eff_len(a->Sk, a->k_half);
   if (lq != lk || lk < 512 || (lk % 512) != 0) return false;

@@ -1186,10 +1186,13 @@ int launch_bwd_dkdv(const BwdParams& p, int dtype, hipStream_t stream) {
   const bool win = windowed(p.causal, p.wl, p.wr);
   if (p.drop_keep < 256)                          // rfa_api.cpp: dropout calls run the 128-key form without spill / window
     return dtype == 0 ? launch_dkdv_d<bf16_t, false, true>(p, stream) : launch_dkdv_d<f16_t, false, true>(p, stream);
+  if (p.wide && p.D == 64 && p.bal)               // (round 6: its balanced causal schedule)
+    return dtype == 0 ? launch_dkdv_t<bf16_t, 64, true, false, false, true, false, true>(p, stream)
+                      : launch_dkdv_t<f16_t, 64, true, false, false, true, false, true>(p, stream);
   if (p.wide && p.D == 64)                        // round 5: the 256-key form for head dim 64 (7-GEMM backward: no dS hand-off there)
     return dtype == 0 ? launch_dkdv_t<bf16_t, 64, true, false, false, true>(p, stream)
                       : launch_dkdv_t<f16_t, 64, true, false, false, true>(p, stream);
-  if (p.wide && p.bal) {                          // round 6: the balanced causal schedule (rfa_api.cpp: head dim 128 only)
+  if (p.wide && p.bal) {                          // round 6: the balanced causal schedule (rfa_api.cpp: head dims 128 and 64)
     if (p.ds != nullptr)
       return dtype == 0 ? launch_dkdv_t<bf16_t, 128, true, true, false, true, false, true>(p, stream)
                         : launch_dkdv_t<f16_t, 128, true, true, false, true, false, true>(p, stream);

@@ -268,7 +268,7 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert plan(args(1, 8192, 8192, 32, 8, causal=True, acc=True, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
     assert plan(args(1, 8192, 8192, 32, 8, causal=True, phases=_C.BWD_COMPUTE, form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
     assert plan(args(1, 8192, 8192, 32, 8, causal=True, window=(512, 0), form=_C.DKDV_BAL))[0] != _C.DKDV_BAL
-    assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True, form=_C.DKDV_BAL)) == (_C.DKDV_256, 2)
+    assert plan(args(1, 8192, 8192, 32, 8, D=96, causal=True, form=_C.DKDV_BAL)) == (_C.DKDV_128, 1)
     # ... overwritten accumulators (the kernel stores fp32 itself) are
     a_ow = args(1, 8192, 8192, 32, 8, causal=True, acc=True)
     a_ow.acc_init = 1
@@ -302,8 +302,9 @@ def test_backward_plan_is_a_function_of_the_arguments(built, monkeypatch):
     assert ws(args(1, 8192, 8192, 32, 8, D=96)) == 0 and ds(args(1, 8192, 8192, 32, 8, D=96)) == 0
     assert plan(args(1, 8192, 8192, 32, 8, D=56, causal=True)) == (_C.DKDV_128, 1)
     # head dim 64 exactly (round 5): the 256-key form by the same shape rules, never a dS hand-off
-    assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == (_C.DKDV_256, 2)
-    assert ws(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == 2 * unit32(8192, 8, 64) and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert plan(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == (_C.DKDV_BAL, 1)
+    assert ws(args(1, 8192, 8192, 32, 8, D=64, causal=True)) == pair_ws(1, 8192, 8, 64) and ds(args(1, 8192, 8192, 32, 8, D=64)) == 0
+    assert plan(args(1, 8192, 4096, 32, 8, D=64)) == (_C.DKDV_256, 2) and ws(args(1, 8192, 4096, 32, 8, D=64)) == 2 * unit32(4096, 8, 64)
     # (no mask: 256 equal workgroups are one balanced round of the chip — nothing to share, no workspace)
     assert plan(args(1, 8192, 8192, 32, 8)) == (_C.DKDV_256, 1) and ws(args(1, 8192, 8192, 32, 8, D=64)) == 0
     assert plan(args(1, 1024, 1024, 4, 2, D=64)) == (_C.DKDV_256, 8)
