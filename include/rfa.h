@@ -134,7 +134,12 @@ typedef struct {
    * (csrc/rfa_fwd.hip: every head dim, windows, dropout; 256 query rows per workgroup — RFA_FWD_AUTO also launches the
    * same kernel with 4 waves / 128 rows on grids that would under-fill the chip, RFA_FWD_4x32 asks for that form wherever
    * it exists: head dim 128 / 64, no window, no dropout).  Value 2 named a 4-wave x 64-row, one-wave-per-SIMD experiment
-   * that lost to the 8 x 32 form by 7 - 13 % in two rounds and was removed in round 6: RFA_ERR_ARGS. */
+   * that lost to the 8 x 32 form by 7 - 13 % in two rounds and was removed in round 6: RFA_ERR_ARGS.
+   * RFA_FWD_P8x32 (ABI 6): the PERSISTENT 256-row form — one workgroup per CU walks its share of the (batch, head, query
+   * block) items, the next item's first K/V tile and Q fragments fetched under the current item's last tile and epilogue.
+   * Head dim 128, dense input (no cu_seqlens) with Sk >= Sq, plain outputs (no out_acc), no window, no dropout, no split-KV
+   * shares; where a call is not eligible the field reads as RFA_FWD_AUTO.  RFA_FWD_AUTO takes it for launches of at least
+   * two items per CU.  Bit-identical to the 8 x 32 form. */
   int32_t fwd_form;
   /* ABI 5 — split-KV launches.  A call with few query rows and many keys (a llama3 head group at 2048 tokens per rank
    * against the gathered keys of 8 ranks: 256 key tiles per workgroup, half the CUs without one) is launched with the
@@ -148,7 +153,7 @@ typedef struct {
   int64_t total_q;
 } rfa_fwd_args;
 
-enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_RETIRED_2 = 2, RFA_FWD_4x32 = 3 };
+enum { RFA_FWD_AUTO = 0, RFA_FWD_8x32 = 1, RFA_FWD_RETIRED_2 = 2, RFA_FWD_4x32 = 3, RFA_FWD_P8x32 = 4 };
 
 typedef struct {
   const void *dout, *out; /* (B,Sq,H,D) io dtype */

@@ -166,9 +166,54 @@ inline void plan_store(uint64_t h, int code) { g_plan_memo[h & 255].store((h << 
 //   * fewer than 64 key tiles, or 257 .. 383 workgroups of 256 rows: the 128-row form, no shares (round 4's rules, confirmed
 //     by the round-6 sweep)
 //   * everything between: the 256-row form with the share count of the smallest estimated makespan
-struct FwdPlan { int rows, ns; };
+struct FwdPlan { int rows, ns, persist; };
+// compute units of the current device (the persistent forward's grid; 256 when no device can be asked: plan queries on a host)
+static int device_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return kPlanSlots;
+  }
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = kPlanSlots;
+  }
+  cached[dev & 63].store(n, std::memory_order_relaxed);
+  return n;
+}
+// the persistent 256-row forward (rfa_fwd.hip: fwd_persist_kernel): what a call must look like
+static bool fwd_persist_eligible(const rfa_fwd_args* a) {
+  if (a->D != kHeadDim || a->cu_seqlens_q != nullptr || a->out_acc != nullptr || a->dropout_p > 0.f) return false;
+  if (a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal))) return false;
+  if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return false;
+  return eff_len(a->Sk, a->k_half) >= eff_len(a->Sq, a->q_half);
+}
+static FwdPlan fwd_plan_base(const rfa_fwd_args* a);
+// Measured (profiles/r06_persistent_forward.md; bit-identical to the 8 x 32 form everywhere): at the headline the seam
+// overlap buys nothing (0.4926 against 0.4905 ms: the dispatcher's own overlap of a finishing and a starting workgroup is as
+// good), from 16384 rows on the static deal loses 1 %; sequences of 1024 .. 2048 rows in launches of >= 2 items per CU gain
+// 1 - 4 % over the best other form (B 8 x S 1024: 0.0861 against 0.0898 for the 128-row form and 0.0941 for the 256-row one).
 static FwdPlan fwd_plan(const rfa_fwd_args* a) {
-  FwdPlan pl{fwd_qrows_per_block(), 1};
+  FwdPlan pl = fwd_plan_base(a);
+  pl.persist = 0;
+  if (!fwd_persist_eligible(a) || a->kv_nsplit > 1) return pl;
+  const int sq = eff_len(a->Sq, a->q_half);
+  const int64_t items = (int64_t)a->B * a->H * ((sq + 255) / 256);
+  const bool by_name = a->fwd_form == RFA_FWD_P8x32;
+  const bool by_rule = a->fwd_form == RFA_FWD_AUTO && pl.ns == 1 && items >= 2 * (int64_t)kPlanSlots && sq >= 1024 && sq <= 2048;
+  if (by_name || by_rule) {
+    pl.rows = 256;
+    pl.ns = 1;
+    pl.persist = 1;
+  }
+  return pl;
+}
+static FwdPlan fwd_plan_base(const rfa_fwd_args* a) {
+  FwdPlan pl{fwd_qrows_per_block(), 1, 0};
   const bool win = a->window && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal));
   if ((a->D != kHeadDim && a->D != kHeadDim / 2) || win || a->dropout_p > 0.f) return pl;   // one form, no shares
   if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0) return pl;
@@ -183,7 +228,7 @@ static FwdPlan fwd_plan(const rfa_fwd_args* a) {
     if (a->fwd_form == RFA_FWD_AUTO) {                      // shares forced, form free: the form the rules below would take
       rfa_fwd_args b = *a;
       b.kv_nsplit = 0;
-      pl.rows = fwd_plan(&b).rows;
+      pl.rows = fwd_plan_base(&b).rows;
     }
     return pl;
   }
@@ -358,7 +403,8 @@ int rfa_fwd(const rfa_fwd_args* a, void* stream) {
   }
   p.qrows = rows;
   p.nqblk = (eff_len(a->Sq, a->q_half) + rows - 1) / rows;
-  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_4x32 || a->fwd_form == RFA_FWD_RETIRED_2) return RFA_ERR_ARGS;
+  p.persist_grid = (plan.persist && rows == 256 && ns <= 1 && plan.ns <= 1) ? device_cus() : 0;
+  if (a->fwd_form < RFA_FWD_AUTO || a->fwd_form > RFA_FWD_P8x32 || a->fwd_form == RFA_FWD_RETIRED_2) return RFA_ERR_ARGS;
   if (a->D > kHeadDim) return launch_status(launch_fwd_big(p, a->dtype, (hipStream_t)stream));
   if (int rc2 = launch_fwd(p, a->dtype, (hipStream_t)stream)) return launch_status(rc2);
   if (ns > 1 && launch_combine(cb, a->dtype, (hipStream_t)stream)) return RFA_ERR_LAUNCH;

@@ -527,6 +527,361 @@ __global__ __launch_bounds__(kW * 64, 2) void fwd_kernel(const FwdParams p) {
   }
 }
 
+// =====================================================================================
+// Persistent forward (round 6, second session): head dim 128, dense input, plain outputs
+// =====================================================================================
+// A 256-row workgroup fills its CU (8 waves, 64 KiB of LDS, two waves per SIMD), so nothing overlaps the ~10 us every
+// workgroup spends outside its tile loop: dispatch, the Q fragment loads and the first K/V tile (an HBM burst of ~100 KB per
+// CU), the epilogue's stores.  The headline launch has 1024 workgroups = FOUR such rounds per CU (the launch-plan estimate
+// prices a round at 8 tile-times; S = 32768 amortises it over 4 x the tiles and runs 6 % faster per FLOP).  Here the grid is
+// one workgroup per CU and each walks its share of the (batch, head, query block) items; the NEXT item's first K/V tile is
+// fetched by the LDS-DMA of the current item's last tile step, its Q fragments are loaded in front of the epilogue (into the
+// registers the last S GEMM has read), and the epilogue's stores stay in flight across the seam (a counted vmcnt: loads
+// retire in order, the 9 stores are the youngest operations).  Items are dealt in passes over the launch's
+// heaviest-first order, every other pass reversed, so that each workgroup's items add up to the same number of tiles (a causal
+// launch: exactly, when the passes are even).  Same arithmetic in the same order per query row as fwd_kernel: bit-identical.
+template <typename T>
+__global__ __launch_bounds__(kFwdWavesMax * 64, 2) void fwd_persist_kernel(const FwdParams p) {
+  constexpr int kD = 128, kW = kFwdWavesMax, kRows = kW * 32;
+  typedef HeadGeo<kD> Geo;
+  constexpr int kRowBytes = Geo::kRowBytes;
+  constexpr int kNK = Geo::kKSteps, kNB = Geo::kDBlocks;
+  constexpr int kTileBytes = kFwdKV * kRowBytes;            // 16 KiB
+  constexpr int kShare = kTileBytes / 1024 / kW;            // 1 KiB DMA pieces per wave and tensor
+  static_assert(kFwdStages == 2 && kFwdKV == 64, "the persistent forward: two LDS stages of 64 keys");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_t* smem = (lds_t*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 5;
+  const int l31 = lane & 31;
+  const int G = p.H / p.Hk;
+
+  // dense input: every (batch, head) has the same spans
+  const SeqSpan qs = resolve_span(nullptr, 0, p.Sq, p.q_half);
+  const SeqSpan ks = resolve_span(nullptr, 0, p.Sk, p.k_half);
+  const int lq = qs.len, lk = ks.len;
+  const int off = lk - lq;                                   // >= 0 (rfa_api.cpp): every query block sees at least one tile
+  const bool hi = p.causal != 0;
+
+  // ---- per-lane constants
+  int voff_k[kShare], voff_v[kShare];
+#pragma unroll
+  for (int i = 0; i < kShare; ++i) {
+    int row, chunk;
+    dma_lane_src<kD>(wave + kW * i, lane, row, chunk);
+    voff_k[i] = (row * (int)p.k_st.row + chunk * 8) * 2;
+    voff_v[i] = (row * (int)p.v_st.row + chunk * 8) * 2;
+  }
+  int koff[kNK];
+#pragma unroll
+  for (int kk = 0; kk < kNK; ++kk) {
+    koff[kk] = lds_addr(smem) + tile_off_d<kD>(l31, 2 * kk + g);
+    pin_vgpr(koff[kk]);
+  }
+  int voff[kNB][2];
+#pragma unroll
+  for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      voff[dblk][hh] = lds_addr(smem) + kFwdStages * kTileBytes + tr_off_d<kD>(lane, dblk, 8 * hh + 4 * g);
+      pin_vgpr(voff[dblk][hh]);
+    }
+  // (per-item lane values — the Q load offset, the store offsets of the epilogue — are formed from an opaque copy of the lane id
+  //  where they are used: hoisted out of the item loop they would be live across the tile loop, whose 218 registers leave
+  //  hipcc just enough room to read the V fragments ahead of their MFMAs)
+  auto opaque_lane = [&]() {
+    int l = threadIdx.x & 63;
+    asm volatile("" : "+v"(l));
+    return l;
+  };
+  const float c = p.scale * kLog2e;
+
+  // ---- items: (kv head fastest, query head in group, query block heaviest first, batch) as fwd_kernel numbers its workgroups
+  const int nitems = p.nqblk * p.H * p.B;
+  const int grid = gridDim.x, bx = blockIdx.x;
+  struct Item {
+    int b, h, hk, qwg0, ntiles;
+  };
+  auto item_at = [&](int pass, Item& it) -> bool {
+    int idx = pass * grid + ((pass & 1) ? grid - 1 - bx : bx);
+    if (idx >= nitems) return false;
+    it.hk = idx % p.Hk;
+    idx /= p.Hk;
+    const int gq = idx % G;
+    idx /= G;
+    int qblk_i;
+    split_block_batch<RFA_BATCH_FAST_Q>(idx, p.nqblk, p.B, qblk_i, it.b);
+    it.h = it.hk * G + gq;
+    it.qwg0 = (p.nqblk - 1 - qblk_i) * kRows;
+    const int qend = (it.qwg0 + kRows < lq) ? it.qwg0 + kRows : lq;
+    int kmax = lk;
+    if (hi && qend + off < kmax) kmax = qend + off;
+    it.ntiles = (kmax + kFwdKV - 1) / kFwdKV;
+    return true;
+  };
+  auto kv_base = [&](const Item& it, const T*& kb, const T*& vb) {
+    kb = (const T*)p.k + (int64_t)it.b * p.k_st.batch + ks.row0 * p.k_st.row + (int64_t)it.hk * p.k_st.head;
+    vb = (const T*)p.v + (int64_t)it.b * p.v_st.batch + ks.row0 * p.v_st.row + (int64_t)it.hk * p.v_st.head;
+  };
+  // a K/V tile (`rows` valid rows at kt / vt; rows past the end of the sequence read as zero) -> LDS stage `stage`
+  const int64_t k_tile_e = (int64_t)kFwdKV * p.k_st.row, v_tile_e = (int64_t)kFwdKV * p.v_st.row;
+  auto dma_rows = [&](const T* kt, const T* vt, int rows, int stage) {
+    const int nk = rows > 0 ? ((rows - 1) * (int)p.k_st.row + kD) * 2 : 0;
+    const int nv = rows > 0 ? ((rows - 1) * (int)p.v_st.row + kD) * 2 : 0;
+    const dma_rsrc_t rk = make_dma_rsrc(kt, nk);
+    const dma_rsrc_t rv = make_dma_rsrc(vt, nv);
+#pragma unroll
+    for (int i = 0; i < kShare; ++i) {
+      const int dst = lds_addr(smem) + stage * kTileBytes + (wave + kW * i) * 1024;
+      dma_load128(rk, dst, voff_k[i]);
+      dma_load128(rv, dst + kFwdStages * kTileBytes, voff_v[i]);
+    }
+  };
+  // this wave's 32 Q rows of an item as B-operand fragments: lane (q = l31, g) holds d = 16 kk + 8 g .. +7; rows past the
+  // end of the sequence are outside the descriptor and read as zero (their results are never stored)
+  vec8<T> qf[kNK];
+  auto load_q = [&](const Item& it) {
+    const int qw0 = it.qwg0 + wave * 32;
+    int rows = lq - qw0;
+    rows = rows < 32 ? rows : 32;
+    const T* qb = (const T*)p.q + (int64_t)it.b * p.q_st.batch + (qs.row0 + qw0) * p.q_st.row + (int64_t)it.h * p.q_st.head;
+    const buf_rsrc_t rq = make_rsrc(rows > 0 ? qb : (const T*)p.q, rows > 0 ? ((rows - 1) * (int)p.q_st.row + kD) * 2 : 0);
+    const int ll = opaque_lane();
+    const int voff_q = ((ll & 31) * (int)p.q_st.row + 8 * (ll >> 5)) * 2;    // this lane's first 16 bytes inside its wave's 32 Q rows
+#pragma unroll
+    for (int kk = 0; kk < kNK; ++kk) qf[kk] = buffer_load128<T>(rq, voff_q + 32 * kk);
+  };
+
+  Item cur;
+  if (!item_at(0, cur)) return;
+  const T *kb, *vb;
+  kv_base(cur, kb, vb);
+  load_q(cur);
+  dma_rows(kb, vb, lk < kFwdKV ? lk : kFwdKV, 0);
+  wait_all_vmem();
+  __syncthreads();
+  int s0 = 0;                                                // LDS stage that holds the current item's tile 0
+
+  for (int pass = 0;; ++pass) {
+    Item nxt;
+    const bool has_next = item_at(pass + 1, nxt);
+    const T *nkb = kb, *nvb = vb;
+    if (has_next) kv_base(nxt, nkb, nvb);
+    const int ntiles = cur.ntiles;
+    const T *run_k = kb + k_tile_e, *run_v = vb + v_tile_e;   // the tile the next step fetches (tile 1 of the current item)
+    const int qw0 = cur.qwg0 + wave * 32;
+    const int qrow = qw0 + l31;
+
+    float m = -INFINITY, mthr = -INFINITY, mc_run = 0.f, lsum = 0.f;
+    f32x16 o[kNB];
+#pragma unroll
+    for (int i = 0; i < kNB; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+
+    auto tile_step = [&](int j, auto stage) {
+      constexpr int kStage = decltype(stage)::value;
+      constexpr int kbo = kStage * kTileBytes, vbo = kStage * kTileBytes;
+      const bool last = j + 1 >= ntiles;
+      if (!last || has_next) {                                       // tile j + 1, or the NEXT item's first tile
+        const int jn = last ? 0 : j + 1;
+        int rows = lk - jn * kFwdKV;
+        rows = rows < kFwdKV ? rows : kFwdKV;
+        dma_rows(last ? nkb : run_k, last ? nvb : run_v, rows, kStage ^ 1);
+        run_k += k_tile_e;
+        run_v += v_tile_e;
+      }
+      const int kt0 = j * kFwdKV;
+      const bool active = (qw0 < lq) && !(hi && kt0 > qw0 + 31 + off);
+      if (active) {
+        f32x16 s[kFwdSub];
+#pragma unroll
+        for (int t = 0; t < kFwdSub; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+        {
+        constexpr int kAhead = RFA_FWD_AHEAD;
+        constexpr int kN = kFwdSub * kNK;
+        vec8<T> a[kN];
+        auto fa = [&](int i) { return lds_read128<T>(lds_ptr(koff[i % kNK]) + kbo + (i / kNK) * 32 * kRowBytes); };
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) a[i] = fa(i);
+#pragma unroll
+        for (int i = 0; i < kN; ++i) {
+          if (i + kAhead < kN) a[i + kAhead] = fa(i + kAhead);
+          s[i / kNK] = mfma(a[i], qf[i % kNK], s[i / kNK]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+        for (int i = 0; i < kN - kAhead; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, kAhead, 0);
+        }
+        const bool need_mask = (kt0 + kFwdKV > lk) || (hi && kt0 + kFwdKV - 1 > qw0 + off);
+        if (need_mask) {
+          const int lim = hi ? ((qrow + off < lk - 1) ? qrow + off : lk - 1) : lk - 1;
+#pragma unroll
+          for (int t = 0; t < kFwdSub; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt0 + 32 * t + crow(r, g);
+              if (key > lim) s[t][r] = -INFINITY;
+            }
+        }
+        float mloc = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[0][r]);
+#pragma unroll
+        for (int t = 1; t < kFwdSub; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[t][r]);
+        mloc = max_xor32(mloc);
+        if (!__all(mloc <= mthr)) {                          // deferred rescale, as fwd_kernel (RFA_FWD_LEAN)
+          const float mnew = fmaxf(m, mloc);
+          const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+          const float alpha = fast_exp2(m * c - msafe * c);
+          m = mnew;
+          mc_run = msafe * c;
+          mthr = mnew + (RFA_FWD_DEFER > 0 ? (float)RFA_FWD_DEFER / c : 0.f);
+          lsum *= alpha;
+#pragma unroll
+          for (int i = 0; i < kNB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float mc = mc_run;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < kFwdSub; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pv = fast_exp2(__builtin_fmaf(s[t][r], c, -mc));
+            s[t][r] = pv;
+            psum += pv;
+          }
+        lsum += psum;
+        // O^T += V^T P^T: the V^T fragments read kAheadV MFMAs ahead, the interleave pinned (left to itself hipcc issues each
+        // pair of transpose reads right in front of its MFMA in this kernel — an lgkmcnt(0) per MFMA)
+        {
+          vec8<T> pb[2 * kFwdSub];
+#pragma unroll
+          for (int x = 0; x < 2 * kFwdSub; ++x) pb[x] = pack8<T>(s[x >> 1], 8 * (x & 1));
+          constexpr int kNV = 2 * kFwdSub * kNB;               // [t][ks2][dblk]
+          constexpr int kAheadV = 3;
+          vec8<T> va[kNV];
+          auto fv = [&](int i) {
+            const int dblk = i % kNB, x = i / kNB;
+            const int imm = vbo + 16 * x * kRowBytes;          // rows 32 t + 16 ks2 = 16 x
+            return concat<T>(lds_read_tr<T>(lds_ptr(voff[dblk][0]) + imm), lds_read_tr<T>(lds_ptr(voff[dblk][1]) + imm));
+          };
+#pragma unroll
+          for (int i = 0; i < kAheadV; ++i) va[i] = fv(i);
+#pragma unroll
+          for (int i = 0; i < kNV; ++i) {
+            if (i + kAheadV < kNV) va[i + kAheadV] = fv(i + kAheadV);
+            o[i % kNB] = mfma(va[i], pb[i / kNB], o[i % kNB]);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, 2 * kAheadV, 1);
+#pragma unroll
+          for (int i = 0; i < kNV - kAheadV; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, kAheadV, 1);
+        }
+      }
+      if (!last) {
+        wait_all_vmem();                                     // tile j + 1 has landed before the barrier publishes it
+        __syncthreads();
+      }
+    };
+    int j = 0;
+    if (s0) {
+      tile_step(0, std::integral_constant<int, 1>{});
+      j = 1;
+    }
+    for (; j < ntiles; j += 2) {
+      tile_step(j, std::integral_constant<int, 0>{});
+      if (j + 1 < ntiles) tile_step(j + 1, std::integral_constant<int, 1>{});
+    }
+
+    // the next item's Q fragments, into the registers the last S GEMM has read for the last time: in flight under the
+    // epilogue.  (NOT inside the last tile step: a load the compiler tracks, issued inside the tile loop, is 'pending' on the
+    // loop's back edge as far as hipcc's waitcnt pass can tell, and it drains the DMA prefetch with a vmcnt(0) in front of
+    // the S GEMM of every tile.)
+    if (has_next) load_q(nxt);
+    // ---- epilogue: normalise, out and lse through range-checked buffer stores (rows past the end of the sequence fall
+    // outside the descriptors): exactly 9 store instructions per wave whatever the rows' validity — the seam's wait counts them
+    {
+      const float l = sum_xor32(lsum);
+      const bool has = l > 0.f;
+      const float inv = has ? 1.f / l : 0.f;
+      const float blse = has ? m * p.scale + __logf(l) : INFINITY;
+      int rows = lq - qw0;
+      rows = rows < 32 ? (rows > 0 ? rows : 0) : 32;
+      T* ob = (T*)p.out + (int64_t)cur.b * p.out_st.batch + (qs.row0 + qw0) * p.out_st.row + (int64_t)cur.h * p.out_st.head;
+      const buf_rsrc_t ro = make_rsrc(rows > 0 ? ob : (T*)p.out, rows > 0 ? ((rows - 1) * (int)p.out_st.row + kD) * 2 : 0);
+      const int ll = opaque_lane();
+      const int vo = ((ll & 31) * (int)p.out_st.row + 8 * (ll >> 5)) * 2;
+#pragma unroll
+      for (int dblk = 0; dblk < kNB; ++dblk)
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+          f32x4 x0, x1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x0[e] = o[dblk][8 * mm + e] * inv;
+            x1[e] = o[dblk][8 * mm + 4 + e] * inv;
+          }
+          const vec4<T> h0 = __builtin_convertvector(x0, vec4<T>);
+          const vec4<T> h1 = __builtin_convertvector(x1, vec4<T>);
+          i32x2 a_ = __builtin_bit_cast(i32x2, h0), b_ = __builtin_bit_cast(i32x2, h1);
+          auto r0 = __builtin_amdgcn_permlane32_swap(a_[0], b_[0], false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(a_[1], b_[1], false, false);
+          u32x4 w;
+          w[0] = r0[0]; w[1] = r1[0]; w[2] = r0[1]; w[3] = r1[1];
+          __builtin_amdgcn_raw_buffer_store_b128(w, ro, vo + (32 * dblk + 16 * mm) * 2, 0, 0);
+        }
+      float* lb = p.lse + (int64_t)cur.b * p.lse_batch + (int64_t)cur.h * p.lse_head + qs.row0 + qw0;
+      const buf_rsrc_t rl = make_rsrc(rows > 0 ? lb : p.lse, rows * 4);
+      // (lanes of the upper half-wave hold the same value: they store it too, to the same address — no exec mask, one instruction)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, blse), rl, (ll & 31) * 4, 0, 0);
+    }
+    if (!has_next) break;
+    // the seam: the next item's tile 0 (DMA) and Q fragments are older than the 9 stores above
+    wait_vmem<9>();
+    // (the fragments re-defined by an empty asm: whatever wait hipcc itself wants for them it places HERE, once per item —
+    //  without it the S GEMM of every tile carries a vmcnt in front of each MFMA)
+#pragma unroll
+    for (int kk = 0; kk < kNK; ++kk) asm volatile("" : "+v"(qf[kk]));
+    __syncthreads();
+    s0 = (s0 + ntiles) & 1;
+    cur = nxt;
+    kb = nkb;
+    vb = nvb;
+  }
+}
+
+template <typename T>
+static int launch_fwd_persist(const FwdParams& p, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  if (int rc = opt_in_dynamic_lds((const void*)fwd_persist_kernel<T>, fwd_smem<128>(), attr_done)) return rc;
+  const int64_t nitems = (int64_t)p.nqblk * p.H * p.B;
+  if (nitems <= 0) return 0;
+#ifdef RFA_PERSIST_ALL                                          // (measurement: one item per workgroup — the tile loop without seams)
+  const int64_t grid = nitems;
+#else
+  const int64_t grid = nitems < p.persist_grid ? nitems : p.persist_grid;
+#endif
+  hipLaunchKernelGGL((fwd_persist_kernel<T>), dim3((unsigned)grid), dim3(kFwdWavesMax * 64), fwd_smem<128>(), stream, p);
+  return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
+}
+
 template <typename T, int kD, bool kFullD, bool kWin, bool kDrop = false, int kW = kFwdWavesMax>
 static int launch_fwd_w(const FwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
@@ -558,6 +913,8 @@ static int launch_fwd_d(const FwdParams& p, hipStream_t stream) {
 }
 
 int launch_fwd(const FwdParams& p, int dtype, hipStream_t stream) {
+  if (p.persist_grid > 0)                                      // rfa_api.cpp: head dim 128, dense, plain outputs, 256-row form, no shares
+    return dtype == 0 ? launch_fwd_persist<bf16_t>(p, stream) : launch_fwd_persist<f16_t>(p, stream);
   if (p.drop_keep < 256)                                       // (rfa_api.cpp rejects dropout together with a window)
     return dtype == 0 ? launch_fwd_d<bf16_t, false, true>(p, stream) : launch_fwd_d<f16_t, false, true>(p, stream);
   if (windowed(p.causal, p.wl, p.wr))

@@ -47,6 +47,7 @@ struct FwdParams {
                        // (causal is folded in by the API layer: wr = 0)
   int nqblk;
   int qrows;           // query rows per workgroup the launch was sized for: 256 (8 waves) or 128 (4 waves, small grids)
+  int persist_grid;    // > 0: the persistent 256-row form (fwd_persist_kernel) with this many workgroups
   // split-KV launches (short query ranges against long key ranges on under-filled grids): the key tiles of a workgroup's
   // range are divided between kv_nsplit workgroups; split s writes a NORMALISED partial (out fp32, lse; -inf = no key)
   // to part_out + s * part_out_split / part_lse + s * part_lse_split (laid out like out_acc / lse_acc), and

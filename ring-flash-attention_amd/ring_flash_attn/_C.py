@@ -17,7 +17,7 @@ BWD_ALL, BWD_COMPUTE, BWD_REDUCE = 0, 1, 2
 BWD_SKIP_DKDV, BWD_SKIP_DQ = 4, 8
 BWD_KV_OVERWRITE = 16     # dk_acc / dv_acc are overwritten (dq_acc still follows acc_init)
 DKDV_AUTO, DKDV_128, DKDV_256, DKDV_BAL = 0, 1, 2, 3
-FWD_AUTO, FWD_8x32, FWD_4x32 = 0, 1, 3        # (2: a retired experiment, RFA_ERR_ARGS)
+FWD_AUTO, FWD_8x32, FWD_4x32, FWD_P8x32 = 0, 1, 3, 4        # (2: a retired experiment, RFA_ERR_ARGS)
 
 
 class Strides(C.Structure):

@@ -434,7 +434,7 @@ def _set_dropout(a, dropout):
     a.q_pos_offset, a.k_pos_offset, a.head_offset = int(q0), int(k0), int(h0)
 
 
-_FWD_FORMS = {"auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x32": _C.FWD_4x32}
+_FWD_FORMS = {"auto": _C.FWD_AUTO, "8x32": _C.FWD_8x32, "4x32": _C.FWD_4x32, "p8x32": _C.FWD_P8x32}
 
 
 def _fwd_form() -> int:

@@ -23,7 +23,7 @@ no `os.environ` lookup on any per-call path.  Three ways to set them:
 | bwd_ds_spill              | RFA_BWD_DS_SPILL                | 1       | 5-GEMM backward (dS hand-off) where eligible; 0: always the 7-GEMM form |
 | ds_spill_max_bytes        | RFA_DS_SPILL_MAX_BYTES          | 4.5 GiB | size of the ONE reusable dS scratch per device and stream; larger hand-offs run in head-group chunks |
 | ds_spill_max_frac         | RFA_DS_SPILL_MAX_FRAC           | 0.5     | ... and never more than this fraction of the memory free when it is first taken |
-| fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 (256 rows) / 4x32 (128 rows) |
+| fwd_form                  | RFA_FWD_FORM                    | auto    | forward kernel form (tuning / tests): auto / 8x32 (256 rows) / 4x32 (128 rows) / p8x32 (persistent 256 rows) |
 | dkdv_wide, dkdv_nsplit    | RFA_DKDV_WIDE, RFA_DKDV_NSPLIT  | unset   | dK/dV launch plan overrides (tuning / tests) |
 | fwd_kv_nsplit             | RFA_FWD_KV_NSPLIT               | 0       | split-KV forward launches: 0 chosen from the shapes, 1 off, 2..8 forced (tuning / tests) |
 | tuning_log                | RFA_TUNING_LOG                  | 0       | print autotune decisions on rank 0 |
@@ -131,7 +131,7 @@ class Config:
         if (r := get("RFA_DS_SPILL_MAX_FRAC")) is not None:
             c.ds_spill_max_frac = _float("RFA_DS_SPILL_MAX_FRAC", r, 0.0, 1.0)
         if (r := get("RFA_FWD_FORM")) is not None:
-            c.fwd_form = _choice("RFA_FWD_FORM", r, ("auto", "8x32", "4x32"))
+            c.fwd_form = _choice("RFA_FWD_FORM", r, ("auto", "8x32", "4x32", "p8x32"))
         if (r := get("RFA_DKDV_WIDE")) is not None:
             c.dkdv_wide = 2 if r.strip() == "2" else (1 if _bool("RFA_DKDV_WIDE", r) else 0)
         if (r := get("RFA_DKDV_NSPLIT")) is not None:

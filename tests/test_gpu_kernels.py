@@ -1117,6 +1117,53 @@ def test_fwd_split_kv_matches_oracle(monkeypatch, B, Sq, Sk, H, Hk, D, causal, n
     assert (res[nsplit][1] - res["1"][1])[torch.isfinite(res["1"][1])].abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("B,Sq,Sk,H,Hk,causal,dtype", [
+    (1, 1000, 1000, 4, 2, True, torch.bfloat16),      # ragged last query block and key tile; 16 items on 256 CUs: one pass
+    (3, 777, 1300, 8, 2, False, torch.float16),       # more keys than queries, fp16
+    (2, 2048, 2048, 48, 8, True, torch.bfloat16),     # 768 items: three passes (the middle one dealt in reverse), GQA 6
+    (1, 4096, 8192, 16, 4, True, torch.bfloat16),     # bottom-right aligned causal mask
+])
+def test_fwd_persistent_form_is_bit_identical(B, Sq, Sk, H, Hk, causal, dtype):
+    """Round 6: the persistent 256-row forward (csrc/rfa_fwd.hip fwd_persist_kernel, RFA_FWD_P8x32): one workgroup per CU walks
+    its share of the (batch, head, query block) items, the next item's first K/V tile and Q fragments fetched under the
+    current item's last tile and epilogue.  Same arithmetic in the same order per query row as the 8 x 32 form: out and lse
+    must be BIT-identical to it (which the reference fixtures and the oracle tests pin), in launches of one and of several
+    passes."""
+    from ring_flash_attn import config
+    from ring_flash_attn.backend import get_backend
+    from ring_flash_attn._testing import set_backend
+
+    set_backend(None)
+    be = get_backend()
+    dev = _dev()
+    D = 128
+    g = torch.Generator().manual_seed(Sq + H)
+    q = torch.randn(B, Sq, H, D, generator=g).to(dtype).to(dev)
+    k = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).to(dev)
+    v = torch.randn(B, Sk, Hk, D, generator=g).to(dtype).to(dev)
+    res = {}
+    for form in ("8x32", "p8x32"):
+        with config.override(fwd_form=form):
+            out = torch.full_like(q, float("nan"))
+            lse = torch.full((B, H, Sq), float("nan"), dtype=torch.float32, device=dev)
+            be.fwd(q, k, v, softmax_scale=D ** -0.5, causal=causal, out=out, lse=lse)
+            res[form] = (out, lse)
+    assert torch.isfinite(res["p8x32"][0]).all() and torch.isfinite(res["p8x32"][1]).all()
+    assert torch.equal(res["p8x32"][0], res["8x32"][0]), "out differs from the 8 x 32 form"
+    assert torch.equal(res["p8x32"][1], res["8x32"][1]), "lse differs from the 8 x 32 form"
+    # a strided kv-packed view and an accumulate-mode call: the first runs the persistent form too, the second is not eligible
+    kv = torch.stack([k, v], dim=2)
+    with config.override(fwd_form="p8x32"):
+        out2 = torch.empty_like(q)
+        lse2 = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+        be.fwd(q, kv[:, :, 0], kv[:, :, 1], softmax_scale=D ** -0.5, causal=causal, out=out2, lse=lse2)
+        assert torch.equal(out2, res["8x32"][0]) and torch.equal(lse2, res["8x32"][1])
+        oacc = torch.zeros((B, Sq, H, D), dtype=torch.float32, device=dev)
+        lacc = torch.empty((B, H, Sq), dtype=torch.float32, device=dev)
+        be.fwd(q, k, v, softmax_scale=D ** -0.5, causal=causal, out_acc=oacc, lse_acc=lacc, acc_init=True)
+        _check("acc-mode out", oacc, res["8x32"][0].float(), 1e-2, 2e-2)
+
+
 @pytest.mark.extended
 def test_fwd_split_kv_packed_sequences(single_rank_group, monkeypatch):
     """split-KV over packed sequences of very different lengths (shares that are empty for the short sequences) through the

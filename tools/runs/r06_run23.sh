@@ -1,0 +1,6 @@
+mkdir -p gpurun_out/r06b
+SH="1,8192,32,8,1 1,8192,32,8,0 4,2048,32,8,1 8,1024,32,8,1"
+for v in base pall base; do
+  if [ $v = base ]; then unset RFA_LIB_PATH; else export RFA_LIB_PATH=build/variants/$v/librfa_hip.so; fi
+  echo "== $v"; timeout 300 python tools/fwd_persist_check.py $SH 2>&1 | grep "^| [0-9]"
+done
