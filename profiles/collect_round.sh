@@ -28,7 +28,11 @@ mkdir -p build/tools
 # (round 6) the limiter read-out beside every phase incl. the MFMA probe's operand re-use patterns, the plan sweep (chosen
 # vs every forced form), the host time inside Agreement.resolve() under a 28-layer stack
 timeout 400 python tools/power_limiters.py --seconds 3 --json $O/${TAG}_power_limiters.json > $O/${TAG}_power_limiters_table.md 2>/dev/null
-timeout 900 python tools/plan_sweep.py > $O/${TAG}_plan_sweep_after.md 2>/dev/null
+timeout 900 python tools/plan_sweep.py > $O/${TAG}_plan_sweep_final.md 2>/dev/null
+# (round 6, second session) the balanced causal dK/dV schedule against the shared-range plans, the persistent forward against
+# the plain forms (parity columns included)
+timeout 300 python tools/bal_check.py 2>/dev/null | grep "^|" > $O/${TAG}_bal_check.md
+timeout 300 python tools/fwd_persist_check.py 2>/dev/null | grep "^|" > $O/${TAG}_fwd_persist_check.md
 timeout 200 python tools/agreement_stall.py > $O/${TAG}_agreement_stall.txt 2>&1
 # wide head dims: the one-launch dK + dV form (head dims <= 192) against one launch per tensor (-DRFA_BG_FUSED2=0) and its variants,
 # when tools/ab_variants.py built them into build/variants/

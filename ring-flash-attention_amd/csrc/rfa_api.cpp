@@ -204,7 +204,30 @@ static FwdPlan fwd_plan(const rfa_fwd_args* a) {
   const int sq = eff_len(a->Sq, a->q_half);
   const int64_t items = (int64_t)a->B * a->H * ((sq + 255) / 256);
   const bool by_name = a->fwd_form == RFA_FWD_P8x32;
-  const bool by_rule = a->fwd_form == RFA_FWD_AUTO && pl.ns == 1 && items >= 2 * (int64_t)kPlanSlots && sq >= 1024 && sq <= 2048;
+  bool by_rule = a->fwd_form == RFA_FWD_AUTO && pl.ns == 1 && items >= 2 * (int64_t)kPlanSlots && sq >= 1024 && sq <= 2048;
+  if (by_rule) {
+    // the static deal must balance: the tiles every workgroup gets from its passes (every other pass reversed, as
+    // fwd_persist_kernel deals them) within 4 % of the mean — whole pairs of passes over a causal launch do exactly; a
+    // partial last pass does not (S 1280 x B 6: 3.75 passes, measured 27 % behind the 256-row form)
+    const int sk = eff_len(a->Sk, a->k_half), off = sk - sq, nq = (sq + 255) / 256, grid = device_cus();
+    std::vector<int64_t> load((size_t)grid, 0);
+    int64_t total = 0;
+    for (int64_t idx = 0; idx < items; ++idx) {
+      const int64_t pass = idx / grid, r = idx % grid;
+      const int64_t w = (pass & 1) ? grid - 1 - r : r;
+      const int64_t blk = idx / ((int64_t)a->H);               // (kv head, query head in group) are the fastest digits
+      const int qblk = nq - 1 - (int)(blk % nq);                // (batch slowest: RFA_BATCH_FAST_Q = 0)
+      const int qend = (qblk + 1) * 256 < sq ? (qblk + 1) * 256 : sq;
+      int kmax = sk;
+      if (a->causal && qend + off < kmax) kmax = qend + off;
+      const int nt = (kmax + 63) / 64 + 8;                     // + the estimate's per-item overhead
+      load[(size_t)w] += nt;
+      total += nt;
+    }
+    int64_t mx = 0;
+    for (int64_t l : load) mx = l > mx ? l : mx;
+    by_rule = mx * grid <= total + total / 25;
+  }
   if (by_name || by_rule) {
     pl.rows = 256;
     pl.ns = 1;
