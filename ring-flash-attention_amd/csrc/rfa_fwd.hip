@@ -28,6 +28,9 @@
 #define RFA_FWD_AHEAD 6      // K fragments read ahead of their MFMA in the S GEMM (round 4 A/B, one box, two passes each:
                              // 2 -> 0.5015 ms, 4 -> 0.4857, 6 -> 0.4835, 8 -> 0.4855)
 #endif
+#ifndef RFA_FWD_AHEAD_V
+#define RFA_FWD_AHEAD_V 3    // persistent forward: V^T fragment pairs read ahead of their MFMA in the P·V GEMM (pinned)
+#endif
 #ifndef RFA_FWD_LEAN
 #define RFA_FWD_LEAN 1       // 1: the deferred-rescale test is ONE compare of the tile's row max against a threshold kept per
                              // row (running max + DEFER / c) and the scaled running max (-m c, the addend of the exponent FMA) is
@@ -772,7 +775,7 @@ __global__ __launch_bounds__(kFwdWavesMax * 64, 2) void fwd_persist_kernel(const
 #pragma unroll
           for (int x = 0; x < 2 * kFwdSub; ++x) pb[x] = pack8<T>(s[x >> 1], 8 * (x & 1));
           constexpr int kNV = 2 * kFwdSub * kNB;               // [t][ks2][dblk]
-          constexpr int kAheadV = 3;
+          constexpr int kAheadV = RFA_FWD_AHEAD_V;
           vec8<T> va[kNV];
           auto fv = [&](int i) {
             const int dblk = i % kNB, x = i / kNB;

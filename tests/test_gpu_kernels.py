@@ -711,7 +711,7 @@ def test_torch_compile_fullgraph_on_gpu(single_rank_group):
     torch._dynamo.reset()
 
 
-@pytest.mark.parametrize("shape", ["dense_5gemm", "dense_small_batch", "varlen"])
+@pytest.mark.parametrize("shape", ["dense_5gemm", "dense_small_batch", "varlen", "dense_balanced"])
 def test_step_under_hip_graph_capture(single_rank_group, shape):
     """a forward + backward of the single-rank step CAPTURED into a HIP graph
     (torch.cuda.graph: allocations from the graph's pool, every launch on the capturing stream) and replayed — the
@@ -730,10 +730,19 @@ def test_step_under_hip_graph_capture(single_rank_group, shape):
                       torch.randn(2048, 8, 128, generator=g).to(BF).to(dev))
         fn = lambda q, kv: R.zigzag_ring_flash_attn_varlen_kvpacked_func(q, kv, cu, 1024, causal=True)
     else:
-        B, S = (1, 2048) if shape == "dense_5gemm" else (8, 512)
-        mk = lambda: (torch.randn(B, S, 8, 128, generator=g).to(BF).to(dev), torch.randn(B, S, 2, 2, 128, generator=g).to(BF).to(dev),
-                      torch.randn(B, S, 8, 128, generator=g).to(BF).to(dev))
+        # dense_balanced (round 6): 4 x 2048 x 32 / 8 heads = 256 key-block workgroups — the balanced causal dK/dV schedule, whose
+        # pair flags are zeroed by a memset NODE in front of the kernel and whose partials meet through agent-scope flags:
+        # every replay must find the flags zero and reproduce the eager bits
+        B, S, H, Hk = {"dense_5gemm": (1, 2048, 8, 2), "dense_small_batch": (8, 512, 8, 2), "dense_balanced": (4, 2048, 32, 8)}[shape]
+        mk = lambda: (torch.randn(B, S, H, 128, generator=g).to(BF).to(dev), torch.randn(B, S, 2, Hk, 128, generator=g).to(BF).to(dev),
+                      torch.randn(B, S, H, 128, generator=g).to(BF).to(dev))
         fn = lambda q, kv: R.zigzag_ring_flash_attn_kvpacked_func(q, kv, causal=True)
+        if shape == "dense_balanced":
+            from ring_flash_attn import _C
+            from ring_flash_attn.backend import get_backend
+            a = _C.BwdArgs()
+            a.B, a.Sq, a.Sk, a.H, a.Hk, a.D, a.dtype, a.causal, a.total_k = B, S, S, H, Hk, 128, 0, 1, B * S
+            assert get_backend().bwd_plan(a)[0] == _C.DKDV_BAL
     q0, kv0, do0 = mk()
     sq, skv, sdo = q0.clone().requires_grad_(True), kv0.clone().requires_grad_(True), do0.clone()
     side = torch.cuda.Stream()
