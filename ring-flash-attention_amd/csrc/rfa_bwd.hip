@@ -1135,6 +1135,11 @@ static int launch_dq_t(const BwdParams& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;
 }
 
+__global__ void zero_words_kernel(unsigned* w, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) w[i] = 0u;
+}
+
 template <typename T, int kD, bool kFullD, bool kSpill, bool kWin, bool kWide = false, bool kDrop = false, bool kBal = false>
 static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
@@ -1143,11 +1148,12 @@ static int launch_dkdv_t(const BwdParams& p, hipStream_t stream) {
   const int64_t nblocks = (int64_t)p.nkblk * p.Hk * p.B * ((kWide && !kBal) ? p.nsplit : 1);
   if (nblocks <= 0) return 0;
   if (kBal) {
-    // the pair flags are polled words: zeroed before EVERY launch (a memset node in front of the kernel, graph-safe)
-    if (hipMemsetAsync(p.pair_flags, 0, (size_t)p.B * p.Hk * (p.nkblk / 2) * sizeof(unsigned), stream) != hipSuccess) {
-      (void)hipGetLastError();
-      return kLaunchFailed;
-    }
+    // the pair flags are polled words: zeroed before EVERY launch, by a kernel of our own in front of the dK/dV kernel —
+    // NOT hipMemsetAsync: captured into a HIP graph (torch.cuda.graph) its memset node left the flags as they were on replay
+    // and every last arriver spun into the trap (tests/test_gpu_kernels.py: test_step_under_hip_graph_capture[dense_balanced])
+    const int nflags = p.B * p.Hk * (p.nkblk / 2);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nflags + 255) / 256)), dim3(256), 0, stream, p.pair_flags, nflags);
+    if (hipGetLastError() != hipSuccess) return kLaunchFailed;
   }
   hipLaunchKernelGGL((dkdv_kernel<T, kD, kFullD, kSpill, kWin, kWide, kDrop, kBal>), dim3((unsigned)nblocks), dim3(kKvThreads), kv_smem<kD>(), stream, p);
   return hipGetLastError() == hipSuccess ? kLaunchOk : kLaunchFailed;

@@ -102,7 +102,7 @@ struct BwdParams {
   int kv_accum;        // fp32 stores ADD to what the partial holds (later query-head fractions of a chunked dS hand-off)
   // balanced causal schedule of the 256-key form (dkdv_kernel kBal; rfa_api.cpp: bwd_dkdv_plan): B * Hk * nkblk / 2 pair
   // slots of 8 waves x 2 tensors x D / 32 x 4 KiB (fp32 accumulators in lane order) and one flag word per pair
-  // (0 = nobody yet, 1 = the first arriver is publishing, 2 = published), zeroed by the launcher before every launch
+  // (0 = nobody yet, 1 = the first arriver is publishing, 2 = published), zeroed by a kernel of the launcher's before every launch
   int bal;
   void* pair_ws;
   unsigned* pair_flags;
